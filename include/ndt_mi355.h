@@ -1,0 +1,184 @@
+/*
+ * ndt_mi355.h — C ABI of the MI355X-native NDT scan-matching engine.
+ *
+ * This is the drop-in boundary for the point-cloud-matching step of
+ * ergevv/lio-slam.  Every entry point names the reference call it replaces
+ * (paths relative to the reference checkout).  The reference does not reach NDT
+ * through an FFI: it holds a `pcl::NormalDistributionsTransform<Point,Point>`
+ * by value (src/slam/include/process.h:86).  A maintainer swaps that member for
+ * the C++ facade in ndt_mi355.hpp, which calls exactly the functions below.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary;
+ *   - every function returns an int status (NDT_OK == 0, negative on error) and
+ *     never throws; ndt_last_error() gives the text of the last failure;
+ *   - point buffers are arrays of records whose first 12 bytes are x,y,z as
+ *     float32 (stride 32 for slam_czc::Point, src/slam/include/utility.h:54-61;
+ *     12 or 16 for packed clouds).  Non-finite points are skipped, as the PCL
+ *     filters in front of the reference NDT do (src/slam/src/process.cc:68-73);
+ *   - point buffers may live in host memory or in device (HBM) memory: the
+ *     engine copies them with hipMemcpyDefault, and the caller's buffer is free
+ *     again when the call returns;
+ *   - 4x4 transforms are double[16], column-major (Eigen's default layout,
+ *     src/slam/src/utility.cc:22-35 builds the guess that way);
+ *   - the 6x6 Hessian is double[36] (symmetric, so row- == column-major) in the
+ *     order [rotation(3), translation(3)] with a right-multiplicative rotation
+ *     perturbation: the coordinates of PointCloudFactor's residual
+ *     (src/slam/include/factor.h:243-251), so it can be passed as `ndt_info`
+ *     (src/slam/src/process.cc:205-211);
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef NDT_MI355_H
+#define NDT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ndt_handle ndt_handle;
+
+enum {
+    NDT_OK = 0,
+    NDT_ERR_INVALID_ARG = -1,
+    NDT_ERR_NO_TARGET = -2,
+    NDT_ERR_NO_SOURCE = -3,
+    NDT_ERR_HIP = -4,
+    NDT_ERR_TOO_FEW_POINTS = -5, /* fewer accepted residuals than min_effective_pts */
+    NDT_ERR_SINGULAR = -6,       /* H not positive definite even after regularisation */
+    NDT_ERR_KEY_RANGE = -7,      /* a coordinate falls outside the 21-bit-per-axis key range */
+    NDT_ERR_COMM = -8,           /* RCCL not available / communicator failure */
+    NDT_ERR_CAPACITY = -9        /* caller-provided output buffer too small */
+};
+
+enum { NDT_KEY_FLOOR_F32 = 0, NDT_KEY_ROUND_F64 = 1 };
+
+/* Replaces the four hard-coded setters at src/slam/src/process.cc:373-376
+ * (setResolution 1.0, setMaximumIterations 35, setTransformationEpsilon 0.01,
+ * setStepSize 0.1 — the last has no Gauss-Newton counterpart) plus the PCL /
+ * SLAM-book defaults listed in SURVEY.md §8(a) row A1/A6. */
+typedef struct ndt_config {
+    float resolution;        /* voxel edge, metres (process.cc:373)                        */
+    int32_t max_iterations;  /* Gauss-Newton iteration cap (process.cc:374)                */
+    double eps;              /* stop when |dx| < eps (process.cc:375); 0 = run all iters   */
+    int32_t nearby;          /* 1 = centre voxel only, 7 = centre + 6 face neighbours      */
+    int32_t min_pts_in_voxel;/* voxel is matched only if it holds >= this many points (6)  */
+    double res_outlier_th;   /* reject a residual when its chi^2 exceeds this (20)         */
+    int32_t min_effective_pts;/* align fails below this many accepted residuals (10)       */
+    int32_t key_rule;        /* NDT_KEY_FLOOR_F32 (PCL voxel grid) | NDT_KEY_ROUND_F64     */
+    double eig_floor_ratio;  /* covariance eigenvalues are raised to ratio*lambda_max (.01)*/
+    int32_t final_eval;      /* 1: re-evaluate H,b,chi2 at the returned pose               */
+    int32_t device;          /* HIP device ordinal                                          */
+} ndt_config;
+
+/* Output of ndt_align.  Replaces getFinalTransformation() (process.cc:95) and
+ * adds what the reference ignores (hasConverged, iteration count) and what the
+ * north star asks for (the Hessian for the Ceres factor). */
+typedef struct ndt_result {
+    double T[16];        /* final pose, column-major 4x4                                   */
+    double H[36];        /* sum J^T Sigma^-1 J, [rot, trans] order                          */
+    double b[6];         /* sum -J^T Sigma^-1 e                                             */
+    double chi2;         /* sum of accepted chi^2                                           */
+    double last_dx_norm; /* |dx| of the last Gauss-Newton step                              */
+    int64_t n_effective; /* accepted residuals in the reported evaluation                   */
+    int32_t iterations;  /* Gauss-Newton steps taken                                        */
+    int32_t converged;   /* 1 if |dx| < eps was reached                                     */
+} ndt_result;
+
+/* Fills *cfg with the defaults chosen in SURVEY.md Appendix B. */
+void ndt_default_config(ndt_config* cfg);
+
+/* Constructor / destructor of the `ndt_` member (process.h:86). */
+ndt_handle* ndt_create(const ndt_config* cfg);
+void ndt_destroy(ndt_handle* h);
+
+/* Re-applies the scalar parameters (the process.cc:373-376 setters) without
+ * touching the resident map or source.  resolution/key_rule/min_pts/eig floor
+ * changes take effect at the next ndt_set_target. */
+int ndt_configure(ndt_handle* h, const ndt_config* cfg);
+
+/* ndt_.setInputTarget(pc_key_) (process.cc:78, 147): discard the resident voxel
+ * map and rebuild it from `n` points. */
+int ndt_set_target(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
+
+/* The keyframe merge of process.cc:134-147 (transformPointCloud + `+=` +
+ * setInputTarget) done incrementally, IncNdt3d::AddCloud style
+ * (src/slam/reference/lio_preinteg.cc:108,133): transform the points by T (NULL
+ * = identity), round to float32, and merge them into the resident voxel hash
+ * with the Gaussian-merge rule of src/slam/reference/math_utils.h:87-98. */
+int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes,
+                   const double T[16]);
+
+/* ndt_.setInputSource(pc_trans_filter) (process.cc:87). */
+int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
+
+/* ndt_.align(*output, guess) + getFinalTransformation() (process.cc:94-95).
+ * Returns NDT_OK also when the iteration cap was hit (out->converged == 0),
+ * as the reference never checks convergence. */
+int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out);
+
+/* One residual/accumulation pass at pose T: the unit of work inside align's
+ * loop; no reference counterpart is callable on its
+ * own.  Any output pointer may be NULL. */
+int ndt_eval(ndt_handle* h, const double T[16], double H[36], double b[6],
+             double* chi2, int64_t* n_effective);
+
+/* Cell assignment of the resident source at pose T, for bit-exact parity
+ * checks: keys[i] is the packed key of point i's centre voxel (or INT64_MIN for
+ * a skipped point), hit_mask[i] has bit j set when probe j found a valid voxel
+ * and its residual passed the chi^2 gate. */
+int ndt_source_cells(ndt_handle* h, const double T[16], int64_t* keys, uint8_t* hit_mask,
+                     size_t cap);
+
+/* Number of source points resident (after non-finite points were dropped). */
+int64_t ndt_source_size(const ndt_handle* h);
+/* Number of voxels resident in the map (valid or not). */
+int64_t ndt_num_voxels(const ndt_handle* h);
+
+/* Dump of the voxel map for key/statistics parity checks; rows are sorted by
+ * packed key.  keys[cap], counts[cap], mean[cap*3], cov[cap*9], info[cap*9]
+ * (info = what the residual kernel reads, zero for voxels that are not valid),
+ * valid[cap].  Any array may be NULL. */
+int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean,
+                      double* cov, double* info, uint8_t* valid, size_t cap, size_t* n_out);
+
+/* Packed-key helpers (21 bits per axis, biased by 2^20). */
+int64_t ndt_pack_key(int32_t ix, int32_t iy, int32_t iz);
+void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz);
+
+/* Offline replay (BASELINE.json configs[4]): align `n_pairs` hypotheses against
+ * the resident map in one batched Gauss-Newton loop.  `pts` holds all scans
+ * back to back; scan s is points [scan_offsets[s], scan_offsets[s+1]);
+ * pair p uses scan pair_scan[p] (NULL: pair p uses scan p) from guesses[16*p]. */
+int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride_bytes,
+                    const int64_t* scan_offsets, size_t n_scans, const int32_t* pair_scan,
+                    size_t n_pairs, const double* guesses, ndt_result* results);
+
+/* Large clouds (BASELINE.json configs[3]): each rank holds a shard of the source
+ * and a replica of the map; ndt_align/ndt_eval then all-reduce the 29 H/b/chi2/n
+ * terms over RCCL on every Gauss-Newton iteration.  Rank 0 calls
+ * ndt_comm_unique_id, the caller distributes the 128 bytes, every rank calls
+ * ndt_comm_init. */
+int ndt_comm_unique_id(char id_out[128]);
+int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]);
+int ndt_comm_destroy(ndt_handle* h);
+
+/* Device-time accounting for benchmarks: total microseconds and launches of the
+ * residual kernel since the last reset, measured with HIP events on the
+ * handle's own stream (enable with ndt_profile(h, 1)). */
+int ndt_profile(ndt_handle* h, int enable);
+int ndt_profile_read(ndt_handle* h, double* residual_kernel_us, int64_t* residual_launches,
+                     double* mean_hits_per_point);
+
+/* Blocks until all work queued on the handle's stream has finished. */
+int ndt_synchronize(ndt_handle* h);
+
+const char* ndt_last_error(const ndt_handle* h);
+const char* ndt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDT_MI355_H */

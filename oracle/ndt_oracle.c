@@ -1,0 +1,653 @@
+/*
+ * ndt_oracle.c — CPU restatement of the NDT scan-matching path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+ * load or call this file.  The product (lio-slam_amd/, include/) never does.
+ *
+ * PARITY UNPINNED against the reference: ergevv/lio-slam holds no NDT source, no
+ * tests and no golden vectors.  Its live path is third-party PCL 1.14
+ * pcl::NormalDistributionsTransform (src/slam/include/process.h:86; calls at
+ * src/slam/src/process.cc:78,87,94,95,147,373-376), absent from this image; the
+ * algorithm family the north star names (voxel-hash Gauss-Newton NDT with
+ * NEARBY1/NEARBY7) is the SLAM-book IncNdt3d/Ndt3d whose header is also absent
+ * (src/slam/reference/lio_preinteg.h:13) — only its call sites
+ * (src/slam/reference/lio_preinteg.cc:37-38,108,116-121,133) and math helpers
+ * (src/slam/reference/math_utils.h) are in the tree.  This file restates that
+ * published algorithm and follows the in-tree pieces line by line where they
+ * exist; it is pinned by the independent float64 NumPy vectors in tests/golden/.
+ *
+ * What follows what:
+ *   voxel key, FLOOR_F32     PCL VoxelGridCovariance grid rule, ijk = floor(p_f32 * inv_leaf_f32)
+ *                            (the cell assignment process.cc:78/147 executes)
+ *   voxel key, ROUND_F64     SLAM-book CastToInt(round(p * inv_res))  
+ *   batch mean / covariance  ComputeMeanAndCov, src/slam/reference/math_utils.h:55-72
+ *                            (mean; sample covariance over (n-1))
+ *   incremental merge        UpdateMeanAndCov, src/slam/reference/math_utils.h:87-98
+ *   hat / Exp                SKEW_SYM_MATRIX and Exp, src/slam/reference/math_utils.h:242-269
+ *   keyframe transform       pcl::transformPointCloud at src/slam/src/process.cc:134-136
+ *   Gauss-Newton align       IncNdt3d::AlignNdt as called at src/slam/reference/lio_preinteg.cc:116-121;
+ *                            parameters from src/slam/src/process.cc:373-376
+ *   H ordering               [rotation, translation], right perturbation: src/slam/include/factor.h:243-251
+ *
+ * Arithmetic contract shared with the HIP engine (this is what makes cell
+ * assignment bit-exact; build with -ffp-contract=off):
+ *   q' = ((R[j][0]*x + R[j][1]*y) + R[j][2]*z) + t[j]      in float64, that order
+ *   source key  = floor(q' * (double)inv_leaf_f32)          (FLOOR) or round() (ROUND)
+ *   target key  = floorf(x_f32 * inv_leaf_f32)              (FLOOR) or round((double)x * inv)
+ *   keyframe pt = (float)q'                                  then keyed as a target point
+ * The voxel table holds, per voxel, what the engine's residual kernel reads:
+ * mean as a float32 offset from the voxel origin key*res, and the six unique
+ * entries of the regularised inverse covariance as float32 (SURVEY.md §8(d):
+ * 40-byte payload).  `quantize = 0` keeps them in float64 instead, which is the
+ * looser "pure double" cross-check in the tests.
+ */
+#include "../include/ndt_mi355.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <pthread.h>
+
+#define KEY_BIAS (1 << 20)
+#define KEY_EMPTY INT64_MIN
+
+typedef struct {
+    int64_t key;
+    int32_t n;
+    int32_t valid;
+    double mean_off[3]; /* mean - key*res */
+    double cov[6];      /* xx xy xz yy yz zz */
+    double pay_off[3];  /* what the residual pass reads (float32-rounded if quantize) */
+    double pay_info[6];
+} ora_voxel;
+
+typedef struct ora_handle {
+    ndt_config cfg;
+    int quantize;
+    /* hash: slot -> voxel index */
+    int64_t* slot_key;
+    int32_t* slot_vox;
+    size_t cap; /* power of two */
+    ora_voxel* vox;
+    size_t n_vox, vox_cap;
+    float* src; /* xyz packed */
+    size_t n_src;
+    float inv_leaf_f32;
+    double inv_res_d, res_d;
+    int n_threads;
+} ora_handle;
+
+/* ---------------------------------------------------------------- keys */
+
+static int64_t pack_key(int32_t ix, int32_t iy, int32_t iz) {
+    return ((int64_t)(ix + KEY_BIAS) << 42) | ((int64_t)(iy + KEY_BIAS) << 21) | (int64_t)(iz + KEY_BIAS);
+}
+static void unpack_key(int64_t k, int32_t* ix, int32_t* iy, int32_t* iz) {
+    *ix = (int32_t)((k >> 42) & 0x1FFFFF) - KEY_BIAS;
+    *iy = (int32_t)((k >> 21) & 0x1FFFFF) - KEY_BIAS;
+    *iz = (int32_t)(k & 0x1FFFFF) - KEY_BIAS;
+}
+static int in_range(double v) { return v >= -(double)KEY_BIAS && v < (double)KEY_BIAS; }
+
+/* PCL grid rule on a float32 map point; returns 0 if out of key range */
+static int target_cell(const ora_handle* h, const float p[3], int32_t c[3]) {
+    for (int j = 0; j < 3; ++j) {
+        double v;
+        if (h->cfg.key_rule == NDT_KEY_FLOOR_F32) {
+            float f = floorf(p[j] * h->inv_leaf_f32);
+            v = (double)f;
+        } else {
+            v = round((double)p[j] * h->inv_res_d);
+        }
+        if (!in_range(v)) return 0;
+        c[j] = (int32_t)v;
+    }
+    return 1;
+}
+/* same rule on a float64 transformed source point */
+static int source_cell(const ora_handle* h, const double q[3], int32_t c[3]) {
+    for (int j = 0; j < 3; ++j) {
+        double v = q[j] * h->inv_res_d;
+        v = (h->cfg.key_rule == NDT_KEY_FLOOR_F32) ? floor(v) : round(v);
+        if (!in_range(v)) return 0;
+        c[j] = (int32_t)v;
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------- hash */
+
+static uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+static int32_t map_find(const ora_handle* h, int64_t key) {
+    if (!h->cap) return -1;
+    size_t m = h->cap - 1, s = (size_t)mix64((uint64_t)key) & m;
+    for (;;) {
+        int64_t k = h->slot_key[s];
+        if (k == key) return h->slot_vox[s];
+        if (k == KEY_EMPTY) return -1;
+        s = (s + 1) & m;
+    }
+}
+static void map_rehash(ora_handle* h, size_t cap) {
+    int64_t* nk = (int64_t*)malloc(cap * sizeof(int64_t));
+    int32_t* nv = (int32_t*)malloc(cap * sizeof(int32_t));
+    for (size_t i = 0; i < cap; ++i) nk[i] = KEY_EMPTY;
+    for (size_t v = 0; v < h->n_vox; ++v) {
+        size_t s = (size_t)mix64((uint64_t)h->vox[v].key) & (cap - 1);
+        while (nk[s] != KEY_EMPTY) s = (s + 1) & (cap - 1);
+        nk[s] = h->vox[v].key; nv[s] = (int32_t)v;
+    }
+    free(h->slot_key); free(h->slot_vox);
+    h->slot_key = nk; h->slot_vox = nv; h->cap = cap;
+}
+static int32_t map_insert(ora_handle* h, int64_t key) {
+    if ((h->n_vox + 1) * 2 > h->cap) map_rehash(h, h->cap ? h->cap * 2 : 1024);
+    if (h->n_vox == h->vox_cap) {
+        h->vox_cap = h->vox_cap ? h->vox_cap * 2 : 1024;
+        h->vox = (ora_voxel*)realloc(h->vox, h->vox_cap * sizeof(ora_voxel));
+    }
+    size_t m = h->cap - 1, s = (size_t)mix64((uint64_t)key) & m;
+    while (h->slot_key[s] != KEY_EMPTY) s = (s + 1) & m;
+    h->slot_key[s] = key; h->slot_vox[s] = (int32_t)h->n_vox;
+    memset(&h->vox[h->n_vox], 0, sizeof(ora_voxel));
+    h->vox[h->n_vox].key = key;
+    return (int32_t)h->n_vox++;
+}
+
+/* ---------------------------------------------------------------- 3x3 symmetric eigen (cyclic Jacobi) */
+
+static void jacobi3(const double c[6], double lam[3], double V[3][3]) {
+    double a[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) { /* A <- A * G */
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; ++k) { /* A <- G^T * A */
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    lam[0] = a[0][0]; lam[1] = a[1][1]; lam[2] = a[2][2];
+}
+
+/* Regularised inverse: eigenvalues below ratio*lambda_max are raised to it
+ * (PCL min_covar_eigvalue_mult_). Returns 0 if the
+ * voxel cannot be used. */
+static int finalize_voxel(const ora_handle* h, ora_voxel* v) {
+    v->valid = 0;
+    memset(v->pay_info, 0, sizeof v->pay_info);
+    for (int j = 0; j < 3; ++j) v->pay_off[j] = h->quantize ? (double)(float)v->mean_off[j] : v->mean_off[j];
+    if (v->n < h->cfg.min_pts_in_voxel) return 0;
+    double lam[3], V[3][3];
+    jacobi3(v->cov, lam, V);
+    double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
+    if (!(lmax > 0.0) || !isfinite(lmax)) return 0;
+    double fl = h->cfg.eig_floor_ratio * lmax;
+    double il[3];
+    for (int j = 0; j < 3; ++j) il[j] = 1.0 / (lam[j] < fl ? fl : lam[j]);
+    double info[6];
+    int t = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c, ++t)
+            info[t] = (V[r][0] * il[0] * V[c][0] + V[r][1] * il[1] * V[c][1]) + V[r][2] * il[2] * V[c][2];
+    for (t = 0; t < 6; ++t) {
+        if (!isfinite(info[t])) return 0;
+        v->pay_info[t] = h->quantize ? (double)(float)info[t] : info[t];
+    }
+    v->valid = 1;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- map build / merge */
+
+typedef struct { int64_t key; uint32_t idx; } key_idx;
+
+/* stable LSD radix sort on the key (ties keep input order = ascending idx) */
+static void sort_key_idx(key_idx* a, size_t n) {
+    key_idx* b = (key_idx*)malloc(n * sizeof(key_idx));
+    for (int pass = 0; pass < 8; ++pass) {
+        size_t cnt[257] = {0};
+        int sh = pass * 8;
+        for (size_t i = 0; i < n; ++i) cnt[(((uint64_t)a[i].key >> sh) & 255) + 1]++;
+        int skip = 0;
+        for (int d = 0; d < 256; ++d) if (cnt[d + 1] == n) skip = 1;
+        if (skip) continue;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; ++i) b[cnt[((uint64_t)a[i].key >> sh) & 255]++] = a[i];
+        memcpy(a, b, n * sizeof(key_idx));
+    }
+    free(b);
+}
+
+/* merge `n` float32 world points into the map */
+static int merge_points(ora_handle* h, const float* p, size_t n) {
+    key_idx* ki = (key_idx*)malloc((n ? n : 1) * sizeof(key_idx));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float* q = p + 3 * i;
+        if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+        int32_t c[3];
+        if (!target_cell(h, q, c)) continue;
+        ki[m].key = pack_key(c[0], c[1], c[2]);
+        ki[m].idx = (uint32_t)i;
+        ++m;
+    }
+    sort_key_idx(ki, m);
+    size_t s = 0;
+    while (s < m) {
+        size_t e = s;
+        int64_t key = ki[s].key;
+        while (e < m && ki[e].key == key) ++e;
+        int32_t c[3];
+        unpack_key(key, &c[0], &c[1], &c[2]);
+        double org[3] = {c[0] * h->res_d, c[1] * h->res_d, c[2] * h->res_d};
+        /* batch statistics in voxel-local coordinates, ComputeMeanAndCov (math_utils.h:55-72) */
+        double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t i = s; i < e; ++i) {
+            const float* q = p + 3 * (size_t)ki[i].idx;
+            double d0 = (double)q[0] - org[0], d1 = (double)q[1] - org[1], d2 = (double)q[2] - org[2];
+            s1[0] += d0; s1[1] += d1; s1[2] += d2;
+            s2[0] += d0 * d0; s2[1] += d0 * d1; s2[2] += d0 * d2;
+            s2[3] += d1 * d1; s2[4] += d1 * d2; s2[5] += d2 * d2;
+        }
+        int32_t nb = (int32_t)(e - s);
+        double mu[3] = {s1[0] / nb, s1[1] / nb, s1[2] / nb};
+        double cv[6] = {0, 0, 0, 0, 0, 0};
+        if (nb > 1) {
+            double dn = (double)(nb - 1);
+            cv[0] = (s2[0] - s1[0] * mu[0]) / dn; cv[1] = (s2[1] - s1[0] * mu[1]) / dn;
+            cv[2] = (s2[2] - s1[0] * mu[2]) / dn; cv[3] = (s2[3] - s1[1] * mu[1]) / dn;
+            cv[4] = (s2[4] - s1[1] * mu[2]) / dn; cv[5] = (s2[5] - s1[2] * mu[2]) / dn;
+        }
+        int32_t vi = map_find(h, key);
+        if (vi < 0) {
+            vi = map_insert(h, key);
+            ora_voxel* v = &h->vox[vi];
+            v->n = nb;
+            memcpy(v->mean_off, mu, sizeof mu);
+            memcpy(v->cov, cv, sizeof cv);
+        } else {
+            /* UpdateMeanAndCov (math_utils.h:87-98) */
+            ora_voxel* v = &h->vox[vi];
+            double hm = (double)v->n, cn = (double)nb, tot = hm + cn;
+            double nm[3], dh[3], dc[3];
+            for (int j = 0; j < 3; ++j) {
+                nm[j] = (hm * v->mean_off[j] + cn * mu[j]) / tot;
+                dh[j] = v->mean_off[j] - nm[j];
+                dc[j] = mu[j] - nm[j];
+            }
+            int t = 0;
+            for (int r = 0; r < 3; ++r)
+                for (int cc = r; cc < 3; ++cc, ++t)
+                    v->cov[t] = (hm * (v->cov[t] + dh[r] * dh[cc]) + cn * (cv[t] + dc[r] * dc[cc])) / tot;
+            memcpy(v->mean_off, nm, sizeof nm);
+            v->n += nb;
+        }
+        finalize_voxel(h, &h->vox[vi]);
+        s = e;
+    }
+    free(ki);
+    return NDT_OK;
+}
+
+static void gather_xyz(const void* pts, size_t n, size_t stride, float* out) {
+    const unsigned char* b = (const unsigned char*)pts;
+    for (size_t i = 0; i < n; ++i) memcpy(out + 3 * i, b + i * stride, 12);
+}
+
+static void mat_from_T(const double T[16], double R[3][3], double t[3]) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[r][c] = T[c * 4 + r];
+        t[r] = T[12 + r];
+    }
+}
+static void T_from_mat(const double R[3][3], const double t[3], double T[16]) {
+    memset(T, 0, 16 * sizeof(double));
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[c * 4 + r] = R[r][c];
+        T[12 + r] = t[r];
+    }
+    T[15] = 1.0;
+}
+static inline void xform(const double R[3][3], const double t[3], const float p[3], double q[3]) {
+    double x = p[0], y = p[1], z = p[2];
+    for (int j = 0; j < 3; ++j) q[j] = ((R[j][0] * x + R[j][1] * y) + R[j][2] * z) + t[j];
+}
+
+/* ---------------------------------------------------------------- public API */
+
+ora_handle* ora_create(const ndt_config* cfg, int quantize) {
+    ora_handle* h = (ora_handle*)calloc(1, sizeof(ora_handle));
+    h->cfg = *cfg;
+    h->quantize = quantize;
+    h->inv_leaf_f32 = 1.0f / cfg->resolution;
+    h->inv_res_d = (double)h->inv_leaf_f32;
+    h->res_d = (double)cfg->resolution;
+    h->n_threads = 1;
+    return h;
+}
+static void map_clear(ora_handle* h) {
+    free(h->slot_key); free(h->slot_vox); free(h->vox);
+    h->slot_key = NULL; h->slot_vox = NULL; h->vox = NULL;
+    h->cap = h->n_vox = h->vox_cap = 0;
+}
+void ora_destroy(ora_handle* h) {
+    if (!h) return;
+    map_clear(h);
+    free(h->src);
+    free(h);
+}
+void ora_set_threads(ora_handle* h, int n) { h->n_threads = n < 1 ? 1 : n; }
+void ora_set_params(ora_handle* h, const ndt_config* cfg) {
+    h->cfg.max_iterations = cfg->max_iterations; h->cfg.eps = cfg->eps; h->cfg.nearby = cfg->nearby;
+    h->cfg.res_outlier_th = cfg->res_outlier_th; h->cfg.min_effective_pts = cfg->min_effective_pts;
+    h->cfg.final_eval = cfg->final_eval;
+}
+
+int ora_add_target(ora_handle* h, const void* pts, size_t n, size_t stride, const double T[16]) {
+    float* p = (float*)malloc((n ? n : 1) * 12);
+    gather_xyz(pts, n, stride, p);
+    if (T) { /* pcl::transformPointCloud, process.cc:134-136; result stored as float32 */
+        double R[3][3], t[3];
+        mat_from_T(T, R, t);
+        for (size_t i = 0; i < n; ++i) {
+            double q[3];
+            xform(R, t, p + 3 * i, q);
+            p[3 * i] = (float)q[0]; p[3 * i + 1] = (float)q[1]; p[3 * i + 2] = (float)q[2];
+        }
+    }
+    int rc = merge_points(h, p, n);
+    free(p);
+    return rc;
+}
+int ora_set_target(ora_handle* h, const void* pts, size_t n, size_t stride) {
+    map_clear(h);
+    return ora_add_target(h, pts, n, stride, NULL);
+}
+int ora_set_source(ora_handle* h, const void* pts, size_t n, size_t stride) {
+    free(h->src);
+    h->src = (float*)malloc((n ? n : 1) * 12);
+    const unsigned char* b = (const unsigned char*)pts;
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float q[3];
+        memcpy(q, b + i * stride, 12);
+        if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+        memcpy(h->src + 3 * m, q, 12);
+        ++m;
+    }
+    h->n_src = m;
+    return NDT_OK;
+}
+int64_t ora_source_size(const ora_handle* h) { return (int64_t)h->n_src; }
+int64_t ora_num_voxels(const ora_handle* h) { return (int64_t)h->n_vox; }
+
+static const int NB7[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+
+/* acc: 21 upper-tri H (row-major), 6 b, chi2, n_eff, hits(total voxel hits incl. gated) */
+static void eval_range(const ora_handle* h, const double R[3][3], const double t[3], size_t i0, size_t i1,
+                       double acc[32], int64_t* keys, uint8_t* masks) {
+    memset(acc, 0, 32 * sizeof(double));
+    const int k = h->cfg.nearby == 7 ? 7 : 1;
+    const double th = h->cfg.res_outlier_th;
+    for (size_t i = i0; i < i1; ++i) {
+        const float* p = h->src + 3 * i;
+        double q[3];
+        xform(R, t, p, q);
+        int32_t c[3];
+        if (!source_cell(h, q, c)) {
+            if (keys) { keys[i] = KEY_EMPTY; masks[i] = 0; }
+            continue;
+        }
+        double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        uint8_t mask = 0;
+        for (int pr = 0; pr < k; ++pr) {
+            int32_t n0 = c[0] + NB7[pr][0], n1 = c[1] + NB7[pr][1], n2 = c[2] + NB7[pr][2];
+            if (!in_range(n0) || !in_range(n1) || !in_range(n2)) continue;
+            int32_t vi = map_find(h, pack_key(n0, n1, n2));
+            if (vi < 0) continue;
+            const ora_voxel* v = &h->vox[vi];
+            if (!v->valid) continue;
+            acc[30] += 1.0;
+            double e0 = (q[0] - (double)n0 * h->res_d) - v->pay_off[0];
+            double e1 = (q[1] - (double)n1 * h->res_d) - v->pay_off[1];
+            double e2 = (q[2] - (double)n2 * h->res_d) - v->pay_off[2];
+            const double* I = v->pay_info;
+            double g0 = (I[0] * e0 + I[1] * e1) + I[2] * e2;
+            double g1 = (I[1] * e0 + I[3] * e1) + I[4] * e2;
+            double g2 = (I[2] * e0 + I[4] * e1) + I[5] * e2;
+            double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
+            if (isnan(chi2) || chi2 > th) continue;
+            mask |= (uint8_t)(1u << pr);
+            for (int j = 0; j < 6; ++j) S[j] += I[j];
+            g[0] += g0; g[1] += g1; g[2] += g2;
+            acc[27] += chi2;
+            acc[28] += 1.0;
+        }
+        if (keys) { keys[i] = pack_key(c[0], c[1], c[2]); masks[i] = mask; }
+        if (!mask) continue;
+        /* J = [ -R*hat(p) | I ]  (right perturbation; SKEW_SYM_MATRIX math_utils.h:242-247) */
+        double x = p[0], y = p[1], z = p[2];
+        double A[3][3];
+        for (int r = 0; r < 3; ++r) {
+            A[r][0] = -(R[r][1] * z - R[r][2] * y);
+            A[r][1] = -(R[r][2] * x - R[r][0] * z);
+            A[r][2] = -(R[r][0] * y - R[r][1] * x);
+        }
+        double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+        double SA[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc) SA[r][cc] = (Sm[r][0] * A[0][cc] + Sm[r][1] * A[1][cc]) + Sm[r][2] * A[2][cc];
+        /* H layout (upper tri, row-major): rows 0..2 = rotation, 3..5 = translation */
+        double Hf[6][6];
+        memset(Hf, 0, sizeof Hf);
+        for (int r = 0; r < 3; ++r)
+            for (int cc = r; cc < 3; ++cc)
+                Hf[r][cc] = (A[0][r] * SA[0][cc] + A[1][r] * SA[1][cc]) + A[2][r] * SA[2][cc];
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc) Hf[r][3 + cc] = SA[cc][r]; /* A^T S */
+        for (int r = 0; r < 3; ++r)
+            for (int cc = r; cc < 3; ++cc) Hf[3 + r][3 + cc] = Sm[r][cc];
+        int tix = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int cc = r; cc < 6; ++cc, ++tix) acc[tix] += Hf[r][cc];
+        for (int r = 0; r < 3; ++r) acc[21 + r] += -((A[0][r] * g[0] + A[1][r] * g[1]) + A[2][r] * g[2]);
+        for (int r = 0; r < 3; ++r) acc[24 + r] += -g[r];
+    }
+}
+
+typedef struct { const ora_handle* h; const double (*R)[3]; const double* t; size_t i0, i1; double acc[32]; } eval_job;
+static void* eval_thread(void* a) {
+    eval_job* j = (eval_job*)a;
+    eval_range(j->h, j->R, j->t, j->i0, j->i1, j->acc, NULL, NULL);
+    return NULL;
+}
+
+static void eval_pose(const ora_handle* h, const double R[3][3], const double t[3], double acc[32]) {
+    int nt = h->n_threads;
+    if (nt <= 1 || h->n_src < 4096) { eval_range(h, R, t, 0, h->n_src, acc, NULL, NULL); return; }
+    eval_job* jobs = (eval_job*)calloc((size_t)nt, sizeof(eval_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t));
+    for (int i = 0; i < nt; ++i) {
+        jobs[i].h = h; jobs[i].R = R; jobs[i].t = t;
+        jobs[i].i0 = h->n_src * (size_t)i / (size_t)nt;
+        jobs[i].i1 = h->n_src * (size_t)(i + 1) / (size_t)nt;
+        pthread_create(&th[i], NULL, eval_thread, &jobs[i]);
+    }
+    memset(acc, 0, 32 * sizeof(double));
+    for (int i = 0; i < nt; ++i) { /* fixed-order final sum */
+        pthread_join(th[i], NULL);
+        for (int j = 0; j < 32; ++j) acc[j] += jobs[i].acc[j];
+    }
+    free(jobs); free(th);
+}
+
+static void unpack_acc(const double acc[32], double H[36], double b[6]) {
+    int t = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c, ++t) { H[r * 6 + c] = acc[t]; H[c * 6 + r] = acc[t]; }
+    for (int r = 0; r < 6; ++r) b[r] = acc[21 + r];
+}
+
+int ora_eval(ora_handle* h, const double T[16], double H[36], double b[6], double* chi2, int64_t* n_eff,
+             double* hits) {
+    if (!h->n_vox) return NDT_ERR_NO_TARGET;
+    if (!h->src) return NDT_ERR_NO_SOURCE;
+    double R[3][3], t[3], acc[32], Hf[36], bf[6];
+    mat_from_T(T, R, t);
+    eval_pose(h, R, t, acc);
+    unpack_acc(acc, Hf, bf);
+    if (H) memcpy(H, Hf, sizeof Hf);
+    if (b) memcpy(b, bf, sizeof bf);
+    if (chi2) *chi2 = acc[27];
+    if (n_eff) *n_eff = (int64_t)acc[28];
+    if (hits) *hits = acc[30];
+    return NDT_OK;
+}
+
+int ora_source_cells(ora_handle* h, const double T[16], int64_t* keys, uint8_t* masks) {
+    if (!h->n_vox) return NDT_ERR_NO_TARGET;
+    if (!h->src) return NDT_ERR_NO_SOURCE;
+    double R[3][3], t[3], acc[32];
+    mat_from_T(T, R, t);
+    eval_range(h, R, t, 0, h->n_src, acc, keys, masks);
+    return NDT_OK;
+}
+
+/* 6x6 SPD solve by Cholesky; returns 0 if a pivot is not positive */
+static int chol_solve6(const double Hin[36], const double b[6], double x[6]) {
+    double L[6][6];
+    memset(L, 0, sizeof L);
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = Hin[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0.0)) return 0;
+                L[i][i] = sqrt(s);
+            } else L[i][j] = s / L[j][j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+    return 1;
+}
+
+/* Exp of math_utils.h:256-269 (Rodrigues; identity below 1e-7 rad) */
+static void so3_exp(const double w[3], double E[3][3]) {
+    double th = sqrt((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[i][j] = (i == j);
+    if (!(th > 1e-7)) return;
+    double a[3] = {w[0] / th, w[1] / th, w[2] / th};
+    double K[3][3] = {{0, -a[2], a[1]}, {a[2], 0, -a[0]}, {-a[1], a[0], 0}};
+    double s = sin(th), c1 = 1.0 - cos(th);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double kk = (K[i][0] * K[0][j] + K[i][1] * K[1][j]) + K[i][2] * K[2][j];
+            E[i][j] += s * K[i][j] + c1 * kk;
+        }
+}
+
+int ora_align(ora_handle* h, const double guess[16], ndt_result* out) {
+    if (!h->n_vox) return NDT_ERR_NO_TARGET;
+    if (!h->src) return NDT_ERR_NO_SOURCE;
+    double R[3][3], t[3], acc[32], H[36], b[6];
+    mat_from_T(guess, R, t);
+    memset(out, 0, sizeof *out);
+    int rc = NDT_OK;
+    memset(acc, 0, sizeof acc);
+    for (int it = 0; it < h->cfg.max_iterations; ++it) {
+        eval_pose(h, R, t, acc);
+        if ((int64_t)acc[28] < h->cfg.min_effective_pts) { rc = NDT_ERR_TOO_FEW_POINTS; break; }
+        unpack_acc(acc, H, b);
+        double dx[6];
+        if (!chol_solve6(H, b, dx)) { rc = NDT_ERR_SINGULAR; break; }
+        double E[3][3], Rn[3][3];
+        so3_exp(dx, E);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rn[i][j] = (R[i][0] * E[0][j] + R[i][1] * E[1][j]) + R[i][2] * E[2][j];
+        memcpy(R, Rn, sizeof Rn);
+        for (int j = 0; j < 3; ++j) t[j] += dx[3 + j];
+        out->iterations = it + 1;
+        double nrm = 0;
+        for (int j = 0; j < 6; ++j) nrm += dx[j] * dx[j];
+        out->last_dx_norm = sqrt(nrm);
+        if (out->last_dx_norm < h->cfg.eps) { out->converged = 1; break; }
+    }
+    if (rc == NDT_OK && h->cfg.final_eval) eval_pose(h, R, t, acc);
+    unpack_acc(acc, out->H, out->b);
+    out->chi2 = acc[27];
+    out->n_effective = (int64_t)acc[28];
+    T_from_mat(R, t, out->T);
+    return rc;
+}
+
+static int cmp_vox_key(const void* a, const void* b) {
+    int64_t ka = ((const ora_voxel*)a)->key, kb = ((const ora_voxel*)b)->key;
+    return (ka > kb) - (ka < kb);
+}
+
+int ora_export_voxels(ora_handle* h, int64_t* keys, int32_t* counts, double* mean, double* cov, double* info,
+                      uint8_t* valid, size_t cap, size_t* n_out) {
+    if (n_out) *n_out = h->n_vox;
+    if (cap < h->n_vox) return NDT_ERR_CAPACITY;
+    ora_voxel* s = (ora_voxel*)malloc((h->n_vox ? h->n_vox : 1) * sizeof(ora_voxel));
+    memcpy(s, h->vox, h->n_vox * sizeof(ora_voxel));
+    qsort(s, h->n_vox, sizeof(ora_voxel), cmp_vox_key);
+    static const int U[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (size_t i = 0; i < h->n_vox; ++i) {
+        int32_t c[3];
+        unpack_key(s[i].key, &c[0], &c[1], &c[2]);
+        if (keys) keys[i] = s[i].key;
+        if (counts) counts[i] = s[i].n;
+        if (valid) valid[i] = (uint8_t)s[i].valid;
+        for (int r = 0; r < 3; ++r) {
+            if (mean) mean[3 * i + r] = (double)c[r] * h->res_d + s[i].mean_off[r];
+            for (int cc = 0; cc < 3; ++cc) {
+                if (cov) cov[9 * i + 3 * r + cc] = s[i].cov[U[r][cc]];
+                if (info) info[9 * i + 3 * r + cc] = s[i].pay_info[U[r][cc]];
+            }
+        }
+    }
+    free(s);
+    return NDT_OK;
+}
+
+int64_t ora_pack_key(int32_t x, int32_t y, int32_t z) { return pack_key(x, y, z); }
+
+/* key of a single map point / of a single transformed source coordinate, for the key-rule vectors */
+int ora_target_key(ora_handle* h, const float p[3], int32_t c[3]) { return target_cell(h, p, c); }
+int ora_source_key(ora_handle* h, const double q[3], int32_t c[3]) { return source_cell(h, q, c); }

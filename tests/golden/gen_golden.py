@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz — float64 NumPy known-answer vectors for the NDT path.
+
+The reference (ergevv/lio-slam) ships no tests, fixtures or golden vectors for
+this path and its NDT implementation (PCL) is absent, so nothing can be generated
+from the reference itself.  These vectors come from this
+independent NumPy implementation of the published algorithm (np.cov, np.linalg.eigh,
+np.linalg.solve, dict-based voxel map — no code shared with oracle/ndt_oracle.c or the
+HIP engine) and pin the oracle.  Run:  python tests/golden/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from lio_slam_amd import synth  # noqa: E402  (scene generator only; no NDT arithmetic)
+
+NB7 = [(0, 0, 0), (-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)]
+
+
+# ------------------------------------------------------------------ (i) key rules
+def target_keys(p32, res, rule):
+    p32 = np.asarray(p32, np.float32)
+    inv32 = np.float32(1.0) / np.float32(res)
+    if rule == 0:   # PCL: floor(p_f32 * inv_leaf_f32) evaluated in float32
+        return np.floor(p32 * inv32).astype(np.int32)
+    v = p32.astype(np.float64) * np.float64(inv32)   # SLAM-book: round half away from zero
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int32)
+
+
+def source_keys(q64, res, rule):
+    inv = np.float64(np.float32(1.0) / np.float32(res))
+    v = np.asarray(q64, np.float64) * inv
+    if rule == 0:
+        return np.floor(v).astype(np.int32)
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int32)
+
+
+def gen_keys():
+    one_m = np.nextafter(np.float32(1.0), np.float32(0.0))
+    vals = [0.0, -0.0, 0.5, -0.5, 1.0, -1.0, -1e-7, 1e-7, float(one_m), -float(one_m), 1.5, -1.5, 2.5, -2.5,
+            0.49999997, -0.49999997, 0.50000006, 999.99994, -999.99994, 1000.0, -1000.0, 1000.5, -1000.5,
+            3.0000002, -3.0000002, 7.9999995, -7.9999995, 0.25, -0.25, 0.75, -0.75, 123.456, -123.456,
+            1e-30, -1e-30, 65535.996, -65535.996, 0.3, 0.6, 0.9, 1.2, -0.3, -0.6, -0.9, -1.2, 2.0, -2.0,
+            10.5, -10.5, 99.5, -99.5, 0.1, -0.1, 0.2, -0.2, 0.7, -0.7, 4.5, -4.5, 5.4999995, -5.4999995,
+            12.000001, -12.000001, 31.5]
+    v32 = np.array(vals, np.float32)
+    pts = np.stack([v32, np.roll(v32, 1), np.roll(v32, 2)], 1)
+    out = {"points": pts}
+    for res in (1.0, 0.5, 0.3):
+        for rule in (0, 1):
+            out[f"target_r{res}_k{rule}"] = target_keys(pts, res, rule)
+            q = pts.astype(np.float64) + 1e-9      # float64 values that are not float32-representable
+            out[f"source_r{res}_k{rule}"] = source_keys(q, res, rule)
+    out["source_points"] = pts.astype(np.float64) + 1e-9
+    np.savez(os.path.join(HERE, "keys.npz"), **out)
+
+
+# ------------------------------------------------------------------ (ii)/(iii) voxel statistics
+def reg_info(cov, ratio):
+    lam, V = np.linalg.eigh(cov)
+    lam = np.maximum(lam, ratio * lam.max())
+    return (V * lam) @ V.T, (V / lam) @ V.T
+
+
+def gen_voxels():
+    rng = np.random.Generator(np.random.PCG64(7))
+    cells = [(3, -2, 0), (-5, 4, 1), (100, -100, 2), (0, 0, 0)]
+    counts = [6, 7, 50, 5]
+    pts, exp = [], {}
+    for ci, (cell, n) in enumerate(zip(cells, counts)):
+        base = np.array(cell, np.float64)
+        # a thin slab (planar surface) inside the cell -> exercises the eigenvalue floor
+        p = base + np.array([0.5, 0.5, 0.3]) + rng.normal(size=(n, 3)) * np.array([0.2, 0.15, 0.004])
+        p = np.clip(p, base + 0.01, base + 0.99).astype(np.float32)
+        pts.append(p)
+        p64 = p.astype(np.float64)
+        exp[f"n{ci}"] = n
+        exp[f"mean{ci}"] = p64.mean(0)
+        exp[f"cov{ci}"] = np.cov(p64.T)              # sample covariance /(n-1), math_utils.h:55-72
+        creg, info = reg_info(exp[f"cov{ci}"], 0.01)
+        exp[f"covreg{ci}"], exp[f"info{ci}"] = creg, info
+        exp[f"cell{ci}"] = np.array(cell, np.int32)
+    exp["points"] = np.concatenate(pts)
+    exp["counts"] = np.array(counts, np.int32)
+    # (iii) merge: second batch into cells 0..2, UpdateMeanAndCov math_utils.h:87-98
+    pts2 = []
+    for ci, (cell, n2) in enumerate(zip(cells[:3], [9, 1, 20])):
+        base = np.array(cell, np.float64)
+        p = base + np.array([0.4, 0.6, 0.32]) + rng.normal(size=(n2, 3)) * np.array([0.15, 0.2, 0.006])
+        p = np.clip(p, base + 0.01, base + 0.99).astype(np.float32)
+        pts2.append(p)
+        p64 = p.astype(np.float64)
+        m, n = counts[ci], n2
+        mu_h, cov_h = exp[f"mean{ci}"], exp[f"cov{ci}"]
+        mu_c = p64.mean(0)
+        cov_c = np.cov(p64.T) if n2 > 1 else np.zeros((3, 3))
+        mu_n = (m * mu_h + n * mu_c) / (m + n)
+        cov_n = (m * (cov_h + np.outer(mu_h - mu_n, mu_h - mu_n)) +
+                 n * (cov_c + np.outer(mu_c - mu_n, mu_c - mu_n))) / (m + n)
+        exp[f"merged_n{ci}"] = m + n
+        exp[f"merged_mean{ci}"] = mu_n
+        exp[f"merged_cov{ci}"] = cov_n
+        exp[f"merged_info{ci}"] = reg_info(cov_n, 0.01)[1]
+    exp["points2"] = np.concatenate(pts2)
+    np.savez(os.path.join(HERE, "voxels.npz"), **exp)
+
+
+# ------------------------------------------------------------------ (iv) scan pair: H, b, chi2, poses
+def build_map(pts32, res=1.0, min_pts=6, ratio=0.01, quantize=True):
+    keys = target_keys(pts32, res, 0)
+    vox = {}
+    order = np.lexsort((np.arange(len(keys)), keys[:, 2], keys[:, 1], keys[:, 0]))
+    ks = keys[order]
+    bounds = np.flatnonzero(np.any(np.diff(ks, axis=0) != 0, axis=1)) + 1
+    for seg in np.split(order, bounds):
+        k = tuple(int(v) for v in keys[seg[0]])
+        p = pts32[seg].astype(np.float64)
+        n = len(seg)
+        mean = p.mean(0)
+        off = mean - np.array(k, np.float64) * res
+        valid = False
+        info = np.zeros((3, 3))
+        if n >= min_pts:
+            cov = np.cov(p.T)
+            lam = np.linalg.eigvalsh(cov)
+            if lam.max() > 0:
+                info = reg_info(cov, ratio)[1]
+                valid = True
+        if quantize:
+            off = off.astype(np.float32).astype(np.float64)
+            info = info.astype(np.float32).astype(np.float64)
+        vox[k] = (off, info, valid)
+    return vox
+
+
+def hat(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def evaluate(vox, src32, T, nearby, res=1.0, th=20.0):
+    R, t = T[:3, :3], T[:3, 3]
+    s = src32.astype(np.float64)
+    q = np.empty_like(s)
+    for j in range(3):   # the engine's operation order: ((R0 x + R1 y) + R2 z) + t
+        q[:, j] = ((R[j, 0] * s[:, 0] + R[j, 1] * s[:, 1]) + R[j, 2] * s[:, 2]) + t[j]
+    cells = source_keys(q, res, 0)
+    H = np.zeros((6, 6)); b = np.zeros(6); chi2s = 0.0; neff = 0
+    masks = np.zeros(len(s), np.uint8)
+    for i in range(len(s)):
+        J = np.hstack([-R @ hat(s[i]), np.eye(3)])
+        for pr in range(nearby):
+            k = (int(cells[i, 0]) + NB7[pr][0], int(cells[i, 1]) + NB7[pr][1], int(cells[i, 2]) + NB7[pr][2])
+            v = vox.get(k)
+            if v is None or not v[2]:
+                continue
+            e = (q[i] - np.array(k, np.float64) * res) - v[0]
+            c2 = e @ v[1] @ e
+            if np.isnan(c2) or c2 > th:
+                continue
+            masks[i] |= 1 << pr
+            H += J.T @ v[1] @ J
+            b += -J.T @ v[1] @ e
+            chi2s += c2
+            neff += 1
+    return H, b, chi2s, neff, cells, masks
+
+
+def exp_so3(w):
+    th = np.linalg.norm(w)
+    if th <= 1e-7:
+        return np.eye(3)
+    K = hat(w / th)
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def gen_pair():
+    rng = np.random.Generator(np.random.PCG64(11))
+    scene = synth.room_scene(rng)
+    Tm = synth.se3([0, 0, 0.0], [0.0, 0.0, 0.6])
+    Ts = synth.se3([0.01, -0.02, 0.05], [0.35, -0.1, 0.62])
+    m = synth.transform(Tm, synth.scan(scene, "vlp16", Tm, rng))
+    s = synth.scan(scene, "vlp16", Ts, rng)
+    m = m[np.sort(rng.choice(len(m), 6000, replace=False))]
+    s = s[np.sort(rng.choice(len(s), 2000, replace=False))]
+    guess = Ts @ synth.se3([0.01, 0.02, -0.03], [0.15, -0.1, 0.05])
+    out = {"map": m, "scan": s, "guess": guess, "T_true": Ts}
+    for quant in (1, 0):
+        vox = build_map(m, quantize=bool(quant))
+        for nearby in (1, 7):
+            H, b, c2, ne, cells, masks = evaluate(vox, s, guess, nearby)
+            tag = f"q{quant}_n{nearby}"
+            out[f"H_{tag}"], out[f"b_{tag}"], out[f"chi2_{tag}"], out[f"neff_{tag}"] = H, b, c2, ne
+            out[f"cells_{tag}"], out[f"masks_{tag}"] = cells, masks
+        # Gauss-Newton trajectory, NEARBY7, 6 iterations
+        T = guess.copy()
+        poses = []
+        for _ in range(6):
+            H, b, _, _, _, _ = evaluate(vox, s, T, 7)
+            dx = np.linalg.solve(H, b)
+            T = T.copy()
+            T[:3, :3] = T[:3, :3] @ exp_so3(dx[:3])
+            T[:3, 3] = T[:3, 3] + dx[3:]
+            poses.append(T)
+        out[f"poses_q{quant}"] = np.stack(poses)
+    np.savez_compressed(os.path.join(HERE, "pair.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_keys()
+    gen_voxels()
+    gen_pair()
+    print("golden vectors written to", HERE)
