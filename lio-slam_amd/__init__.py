@@ -1,0 +1,264 @@
+"""lio_slam_amd — MI355X-native NDT scan matching for lio-slam's point-cloud-matching step.
+
+Python is only a thin ctypes view of the C ABI in include/ndt_mi355.h (the product is
+libndt_mi355.so, built from lio-slam_amd/csrc/*.hip for gfx950).  The class below mirrors
+the call surface the reference uses on its `pcl::NormalDistributionsTransform ndt_` member
+(src/slam/include/process.h:86; src/slam/src/process.cc:78,87,94,95,147,373-376).
+There is no CPU fallback: if the HIP library is missing or no GPU is present, construction
+raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndt_mi355.so")
+
+NDT_KEY_FLOOR_F32, NDT_KEY_ROUND_F64 = 0, 1
+ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP", -5: "TOO_FEW_POINTS",
+          -6: "SINGULAR", -7: "KEY_RANGE", -8: "COMM", -9: "CAPACITY"}
+
+ABI_SYMBOLS = [
+    "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
+    "ndt_set_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
+    "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_comm_unique_id",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_synchronize",
+    "ndt_last_error", "ndt_version",
+]
+
+
+class NdtError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__(f"{ERRORS.get(rc, rc)}: {msg}")
+        self.rc = rc
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_float), ("max_iterations", C.c_int32), ("eps", C.c_double),
+        ("nearby", C.c_int32), ("min_pts_in_voxel", C.c_int32), ("res_outlier_th", C.c_double),
+        ("min_effective_pts", C.c_int32), ("key_rule", C.c_int32), ("eig_floor_ratio", C.c_double),
+        ("final_eval", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16), ("H", C.c_double * 36), ("b", C.c_double * 6), ("chi2", C.c_double),
+        ("last_dx_norm", C.c_double), ("n_effective", C.c_int64), ("iterations", C.c_int32),
+        ("converged", C.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile libndt_mi355.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the NDT engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.ndt_default_config.argtypes = [C.POINTER(Config)]
+    L.ndt_create.restype = vp
+    L.ndt_create.argtypes = [C.POINTER(Config)]
+    L.ndt_destroy.argtypes = [vp]
+    L.ndt_configure.argtypes = [vp, C.POINTER(Config)]
+    L.ndt_set_target.argtypes = [vp, vp, sz, sz]
+    L.ndt_add_target.argtypes = [vp, vp, sz, sz, vp]
+    L.ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
+    L.ndt_eval.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ndt_source_cells.argtypes = [vp, vp, vp, vp, sz]
+    L.ndt_source_size.restype = C.c_int64
+    L.ndt_source_size.argtypes = [vp]
+    L.ndt_num_voxels.restype = C.c_int64
+    L.ndt_num_voxels.argtypes = [vp]
+    L.ndt_export_voxels.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.ndt_pack_key.restype = C.c_int64
+    L.ndt_pack_key.argtypes = [C.c_int32] * 3
+    L.ndt_unpack_key.argtypes = [C.c_int64, vp, vp, vp]
+    L.ndt_align_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.ndt_comm_unique_id.argtypes = [vp]
+    L.ndt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.ndt_comm_destroy.argtypes = [vp]
+    L.ndt_profile.argtypes = [vp, C.c_int]
+    L.ndt_profile_read.argtypes = [vp, vp, vp, vp]
+    L.ndt_synchronize.argtypes = [vp]
+    L.ndt_last_error.restype = C.c_char_p
+    L.ndt_last_error.argtypes = [vp]
+    L.ndt_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_config(**kw):
+    cfg = Config()
+    lib().ndt_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _T(T):
+    """4x4 numpy pose -> column-major double[16] (Eigen's layout)."""
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("pose must be 4x4")
+    return np.ascontiguousarray(T.T).reshape(16)
+
+
+def _points(pts):
+    """(pointer, n, stride) of a point buffer: a float32 numpy array (n, >=3), or (device_ptr, n, stride)."""
+    if isinstance(pts, tuple):
+        ptr, n, stride = pts
+        return None, int(ptr), int(n), int(stride)
+    a = np.ascontiguousarray(pts, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("points must be (n, >=3) float32")
+    return a, a.ctypes.data, a.shape[0], a.shape[1] * 4
+
+
+class NDT:
+    """Mirror of the reference's NDT member: set target, set source, align from a guess, read pose + Hessian.
+
+    Reference setter -> here: setResolution -> resolution, setMaximumIterations -> max_iterations,
+    setTransformationEpsilon -> eps, setStepSize -> accepted and ignored (Gauss-Newton has no line search).
+    """
+
+    def __init__(self, **cfg):
+        self.cfg = default_config(**cfg)
+        self._h = lib().ndt_create(C.byref(self.cfg))
+        if not self._h:
+            raise NdtError(-4, "ndt_create failed (no MI355X visible, or bad config)")
+        self.final = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ndt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NdtError(rc, lib().ndt_last_error(self._h).decode())
+
+    # --- the reference's setters (process.cc:373-376)
+    def configure(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError(k)
+            setattr(self.cfg, k, v)
+        self._chk(lib().ndt_configure(self._h, C.byref(self.cfg)))
+
+    def setResolution(self, r): self.configure(resolution=float(r))
+    def setMaximumIterations(self, n): self.configure(max_iterations=int(n))
+    def setTransformationEpsilon(self, e): self.configure(eps=float(e))
+    def setStepSize(self, s): pass
+
+    # --- clouds
+    def set_target(self, pts):
+        keep, p, n, s = _points(pts)
+        self._chk(lib().ndt_set_target(self._h, p, n, s))
+
+    def add_target(self, pts, T=None):
+        keep, p, n, s = _points(pts)
+        t = None if T is None else _T(T)
+        self._chk(lib().ndt_add_target(self._h, p, n, s, None if t is None else t.ctypes.data))
+
+    def set_source(self, pts):
+        keep, p, n, s = _points(pts)
+        self._chk(lib().ndt_set_source(self._h, p, n, s))
+
+    setInputTarget, setInputSource = set_target, set_source
+
+    def source_size(self): return lib().ndt_source_size(self._h)
+    def num_voxels(self): return lib().ndt_num_voxels(self._h)
+
+    # --- the hot path
+    def eval(self, T):
+        t = _T(T)
+        H = np.zeros((6, 6)); b = np.zeros(6)
+        chi2 = C.c_double(); ne = C.c_int64()
+        self._chk(lib().ndt_eval(self._h, t.ctypes.data, H.ctypes.data, b.ctypes.data, C.addressof(chi2), C.addressof(ne)))
+        return dict(H=H, b=b, chi2=chi2.value, n_effective=ne.value)
+
+    def align(self, guess, check=True):
+        t = _T(guess)
+        r = Result()
+        rc = lib().ndt_align(self._h, t.ctypes.data, C.byref(r))
+        if check:
+            self._chk(rc)
+        self.final = dict(rc=rc, T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6), b=np.array(r.b),
+                          chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations, converged=bool(r.converged),
+                          last_dx_norm=r.last_dx_norm)
+        return self.final
+
+    def getFinalTransformation(self): return self.final["T"]
+    def hasConverged(self): return self.final["converged"]
+    def getFinalNumIteration(self): return self.final["iterations"]
+    def getHessian(self): return self.final["H"]
+
+    def source_cells(self, T):
+        t = _T(T)
+        n = self.source_size()
+        keys = np.zeros(n, np.int64); mask = np.zeros(n, np.uint8)
+        self._chk(lib().ndt_source_cells(self._h, t.ctypes.data, keys.ctypes.data, mask.ctypes.data, n))
+        return keys, mask
+
+    def export_voxels(self):
+        n = self.num_voxels()
+        keys = np.zeros(n, np.int64); cnt = np.zeros(n, np.int32)
+        mean = np.zeros((n, 3)); cov = np.zeros((n, 3, 3)); info = np.zeros((n, 3, 3)); valid = np.zeros(n, np.uint8)
+        no = C.c_size_t()
+        self._chk(lib().ndt_export_voxels(self._h, keys.ctypes.data, cnt.ctypes.data, mean.ctypes.data, cov.ctypes.data,
+                                          info.ctypes.data, valid.ctypes.data, n, C.byref(no)))
+        return dict(keys=keys, counts=cnt, mean=mean, cov=cov, info=info, valid=valid)
+
+    # --- measurement helpers
+    def profile(self, enable=True): self._chk(lib().ndt_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        us = C.c_double(); n = C.c_int64(); hp = C.c_double()
+        self._chk(lib().ndt_profile_read(self._h, C.addressof(us), C.addressof(n), C.addressof(hp)))
+        return dict(residual_us=us.value, launches=n.value, hits_per_point=hp.value)
+
+    def synchronize(self): self._chk(lib().ndt_synchronize(self._h))
+
+    # --- multi-GPU (source sharded across ranks, RCCL all-reduce per iteration)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().ndt_comm_unique_id(buf)
+        if rc:
+            raise NdtError(rc, "ndt_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, n_ranks, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._chk(lib().ndt_comm_init(self._h, rank, n_ranks, buf))
+
+    def comm_destroy(self): self._chk(lib().ndt_comm_destroy(self._h))
+
+
+def unpack_keys(keys):
+    """Packed int64 keys -> (n,3) int32 cells."""
+    k = np.asarray(keys, np.int64)
+    b = 1 << 20
+    return np.stack([((k >> 42) & 0x1FFFFF) - b, ((k >> 21) & 0x1FFFFF) - b, (k & 0x1FFFFF) - b], 1).astype(np.int32)

@@ -1,0 +1,434 @@
+// ndt_api.hip — the C ABI of include/ndt_mi355.h: handle, uploads, the Gauss-Newton driver loop.
+// The host only queues kernels; the pose lives in a GnState in HBM for the whole align, and the host
+// looks at it every SYNC_CHUNK iterations (one 8-byte-aligned D2H copy into pinned memory).
+#include "ndt_internal.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#define SYNC_CHUNK 4
+
+// RCCL is bound at run time (dlopen) so the library loads on hosts without it and never pulls a second
+// copy into a process that already has one.
+typedef int (*pfn_ncclGetUniqueId)(void*);
+struct ndt_nccl_id { char internal[128]; };
+typedef int (*pfn_ncclCommInitRank)(void**, int, ndt_nccl_id, int);
+typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*pfn_ncclCommDestroy)(void*);
+static struct {
+    void* lib;
+    pfn_ncclGetUniqueId get_id;
+    pfn_ncclCommInitRank init_rank;
+    pfn_ncclAllReduce all_reduce;
+    pfn_ncclCommDestroy destroy;
+} g_rccl;
+static bool rccl_load() {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* nm : names) {
+        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return false;
+    g_rccl.get_id = (pfn_ncclGetUniqueId)dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (pfn_ncclCommInitRank)dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.all_reduce = (pfn_ncclAllReduce)dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.destroy = (pfn_ncclCommDestroy)dlsym(g_rccl.lib, "ncclCommDestroy");
+    return g_rccl.get_id && g_rccl.init_rank && g_rccl.all_reduce && g_rccl.destroy;
+}
+enum { NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+struct ndt_handle {
+    ndt_config cfg;
+    hipStream_t stream = nullptr;
+    VoxelMap map;
+    MapWork work;
+    MapBuildCfg build_cfg;      // parameters the resident map was built with
+    bool have_target = false;
+    DevBuf sx, sy, sz, sraw;
+    size_t n_src = 0;
+    bool have_source = false;
+    DevBuf partials, cell_keys, cell_mask;
+    GnState* d_state = nullptr;
+    GnState* h_state = nullptr;  // pinned
+    std::string err;
+    int last_radix_passes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_us = 0.0;
+    int64_t prof_launches = 0;
+    double prof_hits = 0.0, prof_pts = 0.0;
+    // multi-GPU
+    void* comm = nullptr;
+    int n_ranks = 1;
+    DevBuf comm_rows;            // [2][ACC_N] doubles: all-reduce send / receive rows
+};
+
+#define H_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
+
+static KeyParams key_params(const ndt_config& c) {
+    KeyParams kp;
+    kp.inv_leaf_f32 = 1.0f / c.resolution;
+    kp.inv_res_d = (double)kp.inv_leaf_f32;
+    kp.res_d = (double)c.resolution;
+    kp.key_rule = c.key_rule;
+    return kp;
+}
+static int check_cfg(const ndt_config* c, std::string& err) {
+    if (!c) { err = "null config"; return NDT_ERR_INVALID_ARG; }
+    if (!(c->resolution > 0.f) || !isfinite(c->resolution)) { err = "resolution must be positive"; return NDT_ERR_INVALID_ARG; }
+    if (c->nearby != 1 && c->nearby != 7) { err = "nearby must be 1 or 7"; return NDT_ERR_INVALID_ARG; }
+    if (c->max_iterations < 1) { err = "max_iterations must be >= 1"; return NDT_ERR_INVALID_ARG; }
+    if (c->key_rule != NDT_KEY_FLOOR_F32 && c->key_rule != NDT_KEY_ROUND_F64) { err = "unknown key_rule"; return NDT_ERR_INVALID_ARG; }
+    if (c->min_pts_in_voxel < 1) { err = "min_pts_in_voxel must be >= 1"; return NDT_ERR_INVALID_ARG; }
+    if (!(c->eig_floor_ratio > 0.0) || c->eig_floor_ratio > 1.0) { err = "eig_floor_ratio must be in (0,1]"; return NDT_ERR_INVALID_ARG; }
+    return NDT_OK;
+}
+
+extern "C" {
+
+void ndt_default_config(ndt_config* c) {
+    if (!c) return;
+    c->resolution = 1.0f; c->max_iterations = 35; c->eps = 1e-2; c->nearby = 7; c->min_pts_in_voxel = 6;
+    c->res_outlier_th = 20.0; c->min_effective_pts = 10; c->key_rule = NDT_KEY_FLOOR_F32; c->eig_floor_ratio = 0.01;
+    c->final_eval = 1; c->device = 0;
+}
+
+const char* ndt_version(void) { return "ndt_mi355 0.1 (gfx950)"; }
+
+ndt_handle* ndt_create(const ndt_config* cfg) {
+    std::string err;
+    if (check_cfg(cfg, err) != NDT_OK) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return nullptr;
+    if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+    ndt_handle* h = new (std::nothrow) ndt_handle();
+    if (!h) return nullptr;
+    h->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
+        ndt_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void ndt_destroy(ndt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
+    map_free(h->map);
+    h->work.release();
+    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->cell_keys, &h->cell_mask, &h->comm_rows};
+    for (DevBuf* b : bufs) b->release();
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ndt_configure(ndt_handle* h, const ndt_config* cfg) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    int rc = check_cfg(cfg, h->err);
+    if (rc != NDT_OK) return rc;
+    if (cfg->device != h->cfg.device) { h->err = "device cannot change after ndt_create"; return NDT_ERR_INVALID_ARG; }
+    h->cfg = *cfg;
+    return NDT_OK;
+}
+
+static int merge_common(ndt_handle* h, const void* pts, size_t n, size_t stride, const double T[16], bool reset) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    if (reset || !h->have_target) {
+        H_TRY(hipStreamSynchronize(h->stream));
+        map_free(h->map);
+        h->build_cfg.kp = key_params(h->cfg);
+        h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
+        h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+    }
+    double R[9], t[3];
+    if (T) {
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; }
+    }
+    int rc = map_merge_points(h->map, h->work, h->build_cfg, pts, n, stride, T ? R : nullptr, T ? t : nullptr, h->stream,
+                              &h->last_radix_passes, h->err);
+    if (rc == NDT_OK) h->have_target = true;
+    return rc;
+}
+
+int ndt_set_target(ndt_handle* h, const void* pts, size_t n, size_t stride) { return merge_common(h, pts, n, stride, nullptr, true); }
+int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride, const double T[16]) {
+    return merge_common(h, pts, n, stride, T, false);
+}
+
+int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
+    if (n >= (1ull << 31)) { h->err = "more than 2^31 source points"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    H_TRY(h->sraw.ensure(n * stride + 16));
+    H_TRY(h->sx.ensure(n * 4 + 16)); H_TRY(h->sy.ensure(n * 4 + 16)); H_TRY(h->sz.ensure(n * 4 + 16));
+    if (n) {
+        H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
+        H_TRY(unpack_points_soa(h->sraw.p, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
+    }
+    H_TRY(h->partials.ensure((size_t)residual_grid(n) * ACC_N * sizeof(double)));
+    H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
+    h->n_src = n;
+    h->have_source = true;
+    return NDT_OK;
+}
+
+int64_t ndt_source_size(const ndt_handle* h) { return h ? (int64_t)h->n_src : 0; }
+int64_t ndt_num_voxels(const ndt_handle* h) { return h ? h->map.n_vox : 0; }
+
+static void state_from_T(GnState* st, const double T[16]) {
+    memset(st, 0, sizeof *st);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) st->R[3 * r + c] = T[c * 4 + r]; st->t[r] = T[12 + r]; }
+}
+static void T_from_state(const GnState* st, double T[16]) {
+    memset(T, 0, 16 * sizeof(double));
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[c * 4 + r] = st->R[3 * r + c]; T[12 + r] = st->t[r]; }
+    T[15] = 1.0;
+}
+static void unpack_acc(const double* acc, double H[36], double b[6]) {
+    int t = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c, ++t) { if (H) { H[r * 6 + c] = acc[t]; H[c * 6 + r] = acc[t]; } }
+    if (b) for (int r = 0; r < 6; ++r) b[r] = acc[21 + r];
+}
+static int ready(ndt_handle* h) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
+    if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
+    return NDT_OK;
+}
+static EvalParams eval_params(const ndt_handle* h) {
+    EvalParams ep;
+    ep.kp = h->build_cfg.kp;            // the grid the resident map was built on
+    ep.outlier_th = h->cfg.res_outlier_th;
+    ep.nearby = h->cfg.nearby;
+    return ep;
+}
+static SolveParams solve_params(const ndt_handle* h) {
+    SolveParams sp;
+    sp.eps = h->cfg.eps; sp.max_iterations = h->cfg.max_iterations; sp.min_effective_pts = h->cfg.min_effective_pts;
+    return sp;
+}
+
+static hipEvent_t next_event(ndt_handle* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+// queues one residual pass (+ fixed-order reduction, + all-reduce across ranks, + optional GN step)
+static int queue_pass(ndt_handle* h, int do_solve, int force, int64_t* keys_out, uint8_t* mask_out) {
+    const int grid = residual_grid(h->n_src);
+    const EvalParams ep = eval_params(h);
+    const SolveParams sp = solve_params(h);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) { e0 = next_event(h); e1 = next_event(h); if (e0) (void)hipEventRecord(e0, h->stream); }
+    launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.slots, (uint64_t)(h->map.cap - 1),
+                    h->d_state, ep, h->partials.as<double>(), grid, force, keys_out, mask_out, h->stream);
+    if (h->prof && e1) (void)hipEventRecord(e1, h->stream);
+    if (h->comm) {
+        // local fixed-order sum into the send row, all-reduce into the receive row, then the same step on
+        // every rank.  A finished state still takes part in the collective (its rows are ignored), so the
+        // ranks never diverge in the number of collectives they queue.
+        double* send = h->comm_rows.as<double>();
+        double* recv = send + ACC_N;
+        launch_reduce_rows(h->partials.as<double>(), grid, h->d_state, send, force, h->stream);
+        int rc = g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream);
+        if (rc != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
+        launch_solve_only(h->d_state, recv, sp, do_solve, force, h->stream);
+    } else {
+        launch_reduce_solve(h->partials.as<double>(), grid, h->d_state, sp, do_solve, force, h->stream);
+    }
+    H_TRY(hipGetLastError());
+    return NDT_OK;
+}
+static void collect_profile(ndt_handle* h) {
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { h->prof_us += 1e3 * ms; h->prof_launches++; }
+    }
+    h->ev_used = 0;
+}
+
+int ndt_eval(ndt_handle* h, const double T[16], double H[36], double b[6], double* chi2, int64_t* n_eff) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!T) { h->err = "null pose"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    state_from_T(h->h_state, T);
+    H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    if ((rc = queue_pass(h, 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
+    H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    if (h->prof) { collect_profile(h); h->prof_hits += h->h_state->acc[ACC_HITS]; h->prof_pts += (double)h->n_src; }
+    unpack_acc(h->h_state->acc, H, b);
+    if (chi2) *chi2 = h->h_state->acc[ACC_CHI2];
+    if (n_eff) *n_eff = (int64_t)h->h_state->acc[ACC_NEFF];
+    return NDT_OK;
+}
+
+int ndt_source_cells(ndt_handle* h, const double T[16], int64_t* keys, uint8_t* hit_mask, size_t cap) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!T || !keys || !hit_mask) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
+    if (cap < h->n_src) { h->err = "output buffers smaller than the source"; return NDT_ERR_CAPACITY; }
+    if (!h->n_src) return NDT_OK;
+    H_TRY(hipSetDevice(h->cfg.device));
+    H_TRY(h->cell_keys.ensure(h->n_src * 8)); H_TRY(h->cell_mask.ensure(h->n_src));
+    state_from_T(h->h_state, T);
+    H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    void* saved = h->comm; h->comm = nullptr;   // a local diagnostic: no collective
+    rc = queue_pass(h, 0, 1, h->cell_keys.as<int64_t>(), h->cell_mask.as<uint8_t>());
+    h->comm = saved;
+    if (rc != NDT_OK) return rc;
+    H_TRY(hipMemcpyAsync(keys, h->cell_keys.p, h->n_src * 8, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipMemcpyAsync(hit_mask, h->cell_mask.p, h->n_src, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    if (h->prof) collect_profile(h);
+    return NDT_OK;
+}
+
+int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!guess || !out) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    memset(out, 0, sizeof *out);
+    state_from_T(h->h_state, guess);
+    H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    const int max_it = h->cfg.max_iterations;
+    // With eps == 0 the loop cannot stop early: queue everything and look once.
+    const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
+    int queued = 0;
+    while (queued < max_it) {
+        const int m = std::min(chunk, max_it - queued);
+        for (int i = 0; i < m; ++i)
+            if ((rc = queue_pass(h, 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
+        queued += m;
+        H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        if (h->h_state->done) break;
+    }
+    const GnState loop = *h->h_state;
+    if (loop.status == NDT_OK && h->cfg.final_eval) {   // H, b, chi2 at the pose that is returned
+        if ((rc = queue_pass(h, 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
+        H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->prof) collect_profile(h);
+    const GnState* st = h->h_state;
+    T_from_state(st, out->T);
+    unpack_acc(st->acc, out->H, out->b);
+    out->chi2 = st->acc[ACC_CHI2];
+    out->n_effective = (int64_t)st->acc[ACC_NEFF];
+    out->last_dx_norm = loop.dx_norm;
+    out->iterations = loop.iter;
+    out->converged = loop.converged;
+    if (h->prof) { h->prof_hits += st->acc[ACC_HITS]; h->prof_pts += (double)h->n_src; }
+    if (loop.status != NDT_OK) {
+        h->err = loop.status == NDT_ERR_TOO_FEW_POINTS ? "fewer accepted residuals than min_effective_pts" : "Hessian not positive definite";
+        return loop.status;
+    }
+    return NDT_OK;
+}
+
+int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean, double* cov, double* info, uint8_t* valid,
+                      size_t cap, size_t* n_out) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (n_out) *n_out = (size_t)h->map.n_vox;
+    if (!h->have_target) { h->err = "no target"; return NDT_ERR_NO_TARGET; }
+    if (cap < (size_t)h->map.n_vox) { h->err = "output buffers smaller than the map"; return NDT_ERR_CAPACITY; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    std::vector<int64_t> k; std::vector<int32_t> c; std::vector<double> m, cv, inf; std::vector<uint8_t> v;
+    int rc = map_export(h->map, h->build_cfg.kp, k, c, m, cv, inf, v, h->stream, h->err);
+    if (rc != NDT_OK) return rc;
+    const size_t nv = k.size();
+    if (keys) memcpy(keys, k.data(), nv * 8);
+    if (counts) memcpy(counts, c.data(), nv * 4);
+    if (mean) memcpy(mean, m.data(), nv * 24);
+    if (cov) memcpy(cov, cv.data(), nv * 72);
+    if (info) memcpy(info, inf.data(), nv * 72);
+    if (valid) memcpy(valid, v.data(), nv);
+    return NDT_OK;
+}
+
+int64_t ndt_pack_key(int32_t ix, int32_t iy, int32_t iz) { return ndt_pack(ix, iy, iz); }
+void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz) {
+    int32_t a, b, c;
+    ndt_unpack(key, a, b, c);
+    if (ix) *ix = a;
+    if (iy) *iy = b;
+    if (iz) *iz = c;
+}
+
+int ndt_align_batch(ndt_handle* h, const void*, size_t, const int64_t*, size_t, const int32_t*, size_t, const double*, ndt_result*) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    h->err = "ndt_align_batch: not built yet";
+    return NDT_ERR_INVALID_ARG;
+}
+
+int ndt_comm_unique_id(char id_out[128]) {
+    if (!id_out || !rccl_load()) return NDT_ERR_COMM;
+    return g_rccl.get_id(id_out) == 0 ? NDT_OK : NDT_ERR_COMM;
+}
+int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]) {
+    if (!h || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return NDT_ERR_INVALID_ARG;
+    if (!rccl_load()) { h->err = "librccl.so not found"; return NDT_ERR_COMM; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    if (h->comm) { g_rccl.destroy(h->comm); h->comm = nullptr; }
+    ndt_nccl_id uid;
+    memcpy(uid.internal, id, 128);
+    if (g_rccl.init_rank(&h->comm, n_ranks, uid, rank) != 0) { h->comm = nullptr; h->err = "ncclCommInitRank failed"; return NDT_ERR_COMM; }
+    h->n_ranks = n_ranks;
+    H_TRY(h->comm_rows.ensure(2 * ACC_N * sizeof(double)));
+    H_TRY(hipMemsetAsync(h->comm_rows.p, 0, 2 * ACC_N * sizeof(double), h->stream));
+    return NDT_OK;
+}
+int ndt_comm_destroy(ndt_handle* h) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (h->comm) { (void)hipStreamSynchronize(h->stream); g_rccl.destroy(h->comm); h->comm = nullptr; h->n_ranks = 1; }
+    return NDT_OK;
+}
+
+int ndt_profile(ndt_handle* h, int enable) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    h->prof = enable != 0;
+    h->prof_us = 0; h->prof_launches = 0; h->prof_hits = 0; h->prof_pts = 0; h->ev_used = 0;
+    return NDT_OK;
+}
+int ndt_profile_read(ndt_handle* h, double* us, int64_t* launches, double* hits_per_point) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (us) *us = h->prof_us;
+    if (launches) *launches = h->prof_launches;
+    if (hits_per_point) *hits_per_point = h->prof_pts > 0 ? h->prof_hits / h->prof_pts : 0.0;
+    return NDT_OK;
+}
+
+int ndt_synchronize(ndt_handle* h) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    H_TRY(hipSetDevice(h->cfg.device));
+    H_TRY(hipStreamSynchronize(h->stream));
+    return NDT_OK;
+}
+
+const char* ndt_last_error(const ndt_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+}  // extern "C"

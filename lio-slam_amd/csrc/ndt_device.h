@@ -1,0 +1,112 @@
+// ndt_device.h — device-side data layout and small math shared by the engine's kernels.
+//
+// HBM layout:
+//   source cloud    : three float32 arrays x[], y[], z[] (structure of arrays, coalesced 4-byte lanes)
+//   voxel hash      : open addressing, linear probing, power-of-two capacity, one 64-byte VoxSlot per
+//                     slot — key and the 40 payload bytes the residual kernel needs share one slot, so
+//                     a hit costs one 64-byte segment of one 128-byte line
+//   voxel statistics: per slot, float64 running mean offset (3) and covariance (6) + count, used only
+//                     by map build / incremental merge, never by the residual kernel
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NDT_KEY_BIAS (1 << 20)
+#define NDT_KEY_EMPTY INT64_MIN
+
+struct __attribute__((aligned(64))) VoxSlot {
+    int64_t key;    // packed voxel key, NDT_KEY_EMPTY when the slot is free
+    int32_t valid;  // 1: n >= min_pts and the regularised inverse is finite
+    float i22;      // info(2,2)
+    float off[3];   // mean - key*res, float32
+    float i00;      // info upper triangle: 00 01 02 11 12 22
+    float i01, i02, i11, i12;
+    int32_t n;      // points merged into this voxel
+    int32_t pad[3];
+};
+static_assert(sizeof(VoxSlot) == 64, "VoxSlot must be one 64-byte segment");
+
+// accumulator row: 21 upper-triangle H (row-major), 6 b, chi2, n_eff, hits, points
+#define ACC_N 32
+#define ACC_CHI2 27
+#define ACC_NEFF 28
+#define ACC_HITS 29
+#define ACC_PTS 30
+
+struct GnState {          // one per alignment problem, lives in HBM for the whole Gauss-Newton loop
+    double R[9];          // row-major rotation
+    double t[3];
+    double dx[6];
+    double acc[ACC_N];    // reduced accumulators of the last evaluation
+    double dx_norm;
+    int32_t iter;         // Gauss-Newton steps taken
+    int32_t done;         // 1: loop finished (converged, cap reached or failed) -> later launches are no-ops
+    int32_t converged;
+    int32_t status;       // NDT_OK or a negative ndt error
+};
+
+struct KeyParams {
+    float inv_leaf_f32;
+    double inv_res_d;
+    double res_d;
+    int32_t key_rule;     // 0 FLOOR_F32, 1 ROUND_F64
+};
+
+struct EvalParams {
+    KeyParams kp;
+    double outlier_th;
+    int32_t nearby;       // 1 or 7
+};
+
+struct SolveParams {
+    double eps;
+    int32_t max_iterations;
+    int32_t min_effective_pts;
+};
+
+__host__ __device__ inline int64_t ndt_pack(int32_t ix, int32_t iy, int32_t iz) {
+    return ((int64_t)(ix + NDT_KEY_BIAS) << 42) | ((int64_t)(iy + NDT_KEY_BIAS) << 21) |
+           (int64_t)(iz + NDT_KEY_BIAS);
+}
+__host__ __device__ inline void ndt_unpack(int64_t k, int32_t& ix, int32_t& iy, int32_t& iz) {
+    ix = (int32_t)((k >> 42) & 0x1FFFFF) - NDT_KEY_BIAS;
+    iy = (int32_t)((k >> 21) & 0x1FFFFF) - NDT_KEY_BIAS;
+    iz = (int32_t)(k & 0x1FFFFF) - NDT_KEY_BIAS;
+}
+__host__ __device__ inline uint64_t ndt_mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+__device__ inline bool ndt_in_range(double v) { return v >= -(double)NDT_KEY_BIAS && v < (double)NDT_KEY_BIAS; }
+
+// Arithmetic contract with the oracle: plain float64 multiplies and adds in this order,
+// no contraction (the library is built with -ffp-contract=off).
+__device__ inline void ndt_xform(const double* R, const double* t, float xf, float yf, float zf, double q[3]) {
+    double x = xf, y = yf, z = zf;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) q[j] = ((R[3 * j] * x + R[3 * j + 1] * y) + R[3 * j + 2] * z) + t[j];
+}
+// cell of a float32 map point: PCL grid rule floor(p_f32 * inv_leaf_f32) in float32, or round-half-away in f64
+__device__ inline bool ndt_target_cell(const KeyParams& kp, float x, float y, float z, int32_t c[3]) {
+    float p[3] = {x, y, z};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double v = kp.key_rule == 0 ? (double)floorf(p[j] * kp.inv_leaf_f32) : round((double)p[j] * kp.inv_res_d);
+        if (!ndt_in_range(v)) return false;   // also catches NaN / inf
+        c[j] = (int32_t)v;
+    }
+    return true;
+}
+// cell of a float64 transformed source point: same rule evaluated in float64
+__device__ inline bool ndt_source_cell(const KeyParams& kp, const double q[3], int32_t c[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double v = q[j] * kp.inv_res_d;
+        v = kp.key_rule == 0 ? floor(v) : round(v);
+        if (!ndt_in_range(v)) return false;
+        c[j] = (int32_t)v;
+    }
+    return true;
+}

@@ -1,0 +1,75 @@
+// ndt_internal.h — host-side declarations shared by the engine's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ndt_mi355.h"
+#include "ndt_device.h"
+
+struct DevBuf {   // grow-only device allocation
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct VoxelMap {          // the GPU-resident voxel hash
+    VoxSlot* slots = nullptr;
+    double* mean = nullptr;    // [cap*3] running mean offset from the voxel origin
+    double* cov = nullptr;     // [cap*6] running covariance, xx xy xz yy yz zz
+    size_t cap = 0;            // power of two (0 = no map)
+    int64_t n_vox = 0;         // host copy of *d_n_vox
+    int32_t* d_n_vox = nullptr;
+};
+
+struct SortKeyMap {        // packed key <-> compact radix-sort key for one batch
+    int32_t mn[3];
+    int32_t bits[3];
+};
+
+struct MapBuildCfg {
+    KeyParams kp;
+    int32_t min_pts;
+    double eig_floor_ratio;
+};
+
+// ---- ndt_map.hip
+hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s);
+void map_free(VoxelMap& m);
+struct MapWork {
+    DevBuf raw, tx, ty, tz, keys_a, keys_b, vals_a, vals_b, hist, flags, segid, seg_start, scan_tmp, misc;
+    void release() {
+        DevBuf* all[] = {&raw, &tx, &ty, &tz, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &segid, &seg_start, &scan_tmp, &misc};
+        for (DevBuf* b : all) b->release();
+    }
+};
+// Merges n points (raw records, xyz float32 at offset 0 of each `stride`-byte record, host or device
+// memory) into the map; T (device-independent, row-major R | t) may be null.  Returns the number of
+// radix passes executed through *passes.
+int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, size_t n, size_t stride,
+                     const double* R, const double* t, hipStream_t s, int* passes, std::string& err);
+int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& keys, std::vector<int32_t>& counts,
+               std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
+               std::vector<uint8_t>& valid, hipStream_t s, std::string& err);
+hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
+
+// ---- ndt_residual.hip
+int residual_grid(size_t n);
+void launch_residual(const float* x, const float* y, const float* z, int n, const VoxSlot* slots, uint64_t mask,
+                     const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
+                     int64_t* keys_out, uint8_t* mask_out, hipStream_t s);
+void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve,
+                         int force, hipStream_t s);
+void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s);
+void launch_solve_only(GnState* st, const double* reduced, const SolveParams& sp, int do_solve, int force, hipStream_t s);

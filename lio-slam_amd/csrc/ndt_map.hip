@@ -1,0 +1,585 @@
+// ndt_map.hip — target voxel-map build and incremental keyframe merge.
+//
+// Replaces pcl::VoxelGridCovariance::filter (triggered by ndt_.setInputTarget, src/slam/src/process.cc:78,147)
+// and the append + re-downsample + full rebuild of process.cc:134-147 with
+//   keys -> LSD radix sort by compact voxel key -> segment heads -> per-segment statistics
+//   (ComputeMeanAndCov, src/slam/reference/math_utils.h:55-72) -> find-or-insert in the resident hash ->
+//   Gaussian merge (UpdateMeanAndCov, math_utils.h:87-98) -> regularised 3x3 inverse -> 40-byte payload.
+// Every reduction has a fixed order (sorted by (key, input index), 8-lane strided sums, xor tree), so the
+// map is bit-reproducible from run to run; integer atomics are used only for counters, min/max and the
+// hash-slot claim.  All kernels are HBM-bound integer/byte work: coalesced 4/8-byte lanes, no MFMA.
+#include "ndt_internal.h"
+
+#include <algorithm>
+#include <numeric>
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
+
+// ------------------------------------------------------------------ table init / alloc
+
+__global__ void k_init_slots(VoxSlot* s, size_t cap) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    VoxSlot v = {};
+    v.key = NDT_KEY_EMPTY;
+    s[i] = v;
+}
+
+hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&m.slots, cap * sizeof(VoxSlot))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&m.mean, cap * 3 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&m.cov, cap * 6 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&m.d_n_vox, 256)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(m.d_n_vox, 0, 256, s)) != hipSuccess) return e;
+    m.cap = cap;
+    m.n_vox = 0;
+    k_init_slots<<<(unsigned)((cap + 255) / 256), 256, 0, s>>>(m.slots, cap);
+    return hipGetLastError();
+}
+void map_free(VoxelMap& m) {
+    if (m.slots) (void)hipFree(m.slots);
+    if (m.mean) (void)hipFree(m.mean);
+    if (m.cov) (void)hipFree(m.cov);
+    if (m.d_n_vox) (void)hipFree(m.d_n_vox);
+    m = VoxelMap();
+}
+
+// ------------------------------------------------------------------ AoS records -> SoA
+
+__global__ void k_unpack_soa(const unsigned char* raw, size_t n, size_t stride, float* x, float* y, float* z) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = (const float*)(raw + i * stride);   // records are 4-byte aligned
+    x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
+}
+hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s) {
+    if (!n) return hipSuccess;
+    k_unpack_soa<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const unsigned char*)d_raw, n, stride, x, y, z);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ pass 1: world point, packed key, bbox
+
+// misc layout (int32): [0..2] min cell, [3..5] max cell, [6] n_valid, [7] nseg
+__global__ void k_target_keys(const unsigned char* raw, size_t n, size_t stride, int has_T, const double* Rt,
+                              KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
+                              int32_t* misc) {
+    __shared__ int32_t smn[3], smx[3], scnt;
+    if (threadIdx.x < 3) { smn[threadIdx.x] = INT32_MAX; smx[threadIdx.x] = INT32_MIN; }
+    if (threadIdx.x == 0) scnt = 0;
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float* p = (const float*)(raw + i * stride);
+        float x = p[0], y = p[1], z = p[2];
+        bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+        if (ok && has_T) {   // pcl::transformPointCloud (process.cc:134-136): float64 math, one rounding to float32
+            double q[3];
+            ndt_xform(Rt, Rt + 9, x, y, z, q);
+            x = (float)q[0]; y = (float)q[1]; z = (float)q[2];
+        }
+        int32_t c[3];
+        ok = ok && ndt_target_cell(kp, x, y, z, c);
+        tx[i] = x; ty[i] = y; tz[i] = z;
+        vals[i] = (uint32_t)i;
+        keys[i] = ok ? ndt_pack(c[0], c[1], c[2]) : NDT_KEY_EMPTY;
+        if (ok) {
+            atomicAdd(&scnt, 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { atomicMin(&smn[j], c[j]); atomicMax(&smx[j], c[j]); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && scnt) { atomicMin(&misc[threadIdx.x], smn[threadIdx.x]); atomicMax(&misc[3 + threadIdx.x], smx[threadIdx.x]); }
+    if (threadIdx.x == 0 && scnt) atomicAdd(&misc[6], scnt);
+}
+
+// pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
+__global__ void k_sort_keys(int64_t* keys, size_t n, SortKeyMap km) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t k = keys[i];
+    uint64_t sk = ~0ull;
+    if (k != NDT_KEY_EMPTY) {
+        int32_t c[3];
+        ndt_unpack(k, c[0], c[1], c[2]);
+        sk = ((uint64_t)(c[0] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint64_t)(c[1] - km.mn[1]) << km.bits[2]) |
+             (uint64_t)(c[2] - km.mn[2]);
+    }
+    keys[i] = (int64_t)sk;
+}
+__device__ inline int64_t sortkey_to_packed(uint64_t sk, const SortKeyMap& km) {
+    int32_t cz = (int32_t)(sk & ((1ull << km.bits[2]) - 1)) + km.mn[2];
+    int32_t cy = (int32_t)((sk >> km.bits[2]) & ((1ull << km.bits[1]) - 1)) + km.mn[1];
+    int32_t cx = (int32_t)(sk >> (km.bits[1] + km.bits[2])) + km.mn[0];
+    return ndt_pack(cx, cy, cz);
+}
+
+// ------------------------------------------------------------------ exclusive scan (uint32)
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ inline uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();                 // protect wsum across back-to-back calls
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int j = 0; j < w; ++j) base += wsum[j];
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* in, size_t n, uint32_t* bsum) {
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) s += in[base + j];
+    uint32_t tot;
+    block_exclusive_scan_256(s, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// one block: exclusive scan of bsum[0..nb) in place, grand total to *total
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_spine(uint32_t* bsum, size_t nb, uint32_t* total) {
+    uint32_t carry = 0;
+    for (size_t base = 0; base < nb; base += SCAN_THREADS) {
+        size_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? bsum[i] : 0, tot;
+        uint32_t ex = block_exclusive_scan_256(v, &tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const uint32_t* in, uint32_t* out, size_t n, const uint32_t* bsum) {
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    uint32_t ex = block_exclusive_scan_256(s, nullptr) + bsum[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) { if (base + j < n) out[base + j] = ex; ex += v[j]; }
+}
+// out may alias in.  tmp needs ceil(n / SCAN_TILE) + 1 uint32.
+static void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, uint32_t* total, hipStream_t s) {
+    size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (!nb) { if (total) (void)hipMemsetAsync(total, 0, 4, s); return; }
+    k_scan_reduce<<<(unsigned)nb, SCAN_THREADS, 0, s>>>(in, n, tmp);
+    k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(tmp, nb, total);
+    k_scan_down<<<(unsigned)nb, SCAN_THREADS, 0, s>>>(in, out, n, tmp);
+}
+
+// ------------------------------------------------------------------ LSD radix sort, 8-bit digits, (u64 key, u32 value)
+
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+// hist layout: digit-major, hist[d * nblk + blk], so one exclusive scan yields every (digit, block) base
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t* keys, size_t n, int shift, uint32_t* hist, unsigned nblk) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter: element order inside a tile is (round, wave, lane) = input order
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t* keys, const uint32_t* vals, size_t n, int shift,
+                                                              const uint32_t* offs, unsigned nblk, uint64_t* okeys, uint32_t* ovals) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wcnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    running[threadIdx.x] = offs[(size_t)threadIdx.x * nblk + blockIdx.x];
+    size_t base = (size_t)blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
+        __syncthreads();
+        size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        bool act = i < n;
+        uint64_t k = act ? keys[i] : 0;
+        uint32_t v = act ? vals[i] : 0;
+        unsigned d = (unsigned)(k >> shift) & 255u;
+        unsigned long long m = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long bal = __ballot(act && ((d >> b) & 1u));
+            m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (act && rank == 0) wcnt[w][d] = __popcll(m);
+        __syncthreads();
+        if (act) {
+            uint32_t pos = running[d] + rank;
+            for (int j = 0; j < w; ++j) pos += wcnt[j][d];
+            okeys[pos] = k;
+            ovals[pos] = v;
+        }
+        __syncthreads();
+        running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------ segments
+
+__global__ void k_heads(const uint64_t* sk, size_t n, uint32_t* flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || sk[i] != sk[i - 1]) ? 1u : 0u;
+}
+__global__ void k_seg_starts(const uint32_t* flags, const uint32_t* segid, size_t n, uint32_t* seg_start) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) seg_start[segid[i]] = (uint32_t)i;
+    if (i == n - 1) seg_start[segid[i] + flags[i]] = (uint32_t)n;   // = seg_start[nseg]: end of the last run
+}
+
+// 3x3 symmetric eigen-decomposition, cyclic Jacobi (double)
+__device__ inline void jacobi3_dev(const double c[6], double lam[3], double V[3][3]) {
+    double a[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    lam[0] = a[0][0]; lam[1] = a[1][1]; lam[2] = a[2][2];
+}
+
+// regularised 3x3 inverse + float32 payload (what the residual kernel reads)
+__device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3], const double cv[6], int32_t min_pts, double ratio) {
+    float info[6] = {0, 0, 0, 0, 0, 0};
+    int32_t valid = 0;
+    if (n >= min_pts) {
+        double lam[3], V[3][3];
+        jacobi3_dev(cv, lam, V);
+        double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
+        if (lmax > 0.0 && isfinite(lmax)) {
+            double fl = ratio * lmax, il[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) il[j] = 1.0 / (lam[j] < fl ? fl : lam[j]);
+            valid = 1;
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = r; c < 3; ++c, ++t) {
+                    double v = (V[r][0] * il[0] * V[c][0] + V[r][1] * il[1] * V[c][1]) + V[r][2] * il[2] * V[c][2];
+                    if (!isfinite(v)) valid = 0;
+                    info[t] = (float)v;
+                }
+        }
+    }
+    sl->off[0] = (float)mu[0]; sl->off[1] = (float)mu[1]; sl->off[2] = (float)mu[2];
+    if (!valid) { info[0] = info[1] = info[2] = info[3] = info[4] = info[5] = 0.f; }
+    sl->i00 = info[0]; sl->i01 = info[1]; sl->i02 = info[2]; sl->i11 = info[3]; sl->i12 = info[4]; sl->i22 = info[5];
+    sl->n = n;
+    sl->valid = valid;
+}
+
+#define SEG_LANES 8
+// One 8-lane group per segment (= one voxel of the batch): strided sums in voxel-local float64 coordinates,
+// xor-tree over the 8 lanes, then lane 0 claims / finds the hash slot, merges and finalises.
+__global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* sv, const uint32_t* seg_start, uint32_t nseg,
+                                                       const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
+                                                       VoxSlot* slots, double* mean, double* cov, uint64_t mask, int32_t* n_vox) {
+    uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
+    const int l = threadIdx.x % SEG_LANES;
+    bool act = g < nseg;
+    uint32_t s = 0, e = 0;
+    int64_t key = 0;
+    double org[3] = {0, 0, 0};
+    if (act) {
+        s = seg_start[g]; e = seg_start[g + 1];
+        key = sortkey_to_packed(sk[s], km);
+        int32_t c[3];
+        ndt_unpack(key, c[0], c[1], c[2]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) org[j] = (double)c[j] * cfg.kp.res_d;
+    }
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = s + l; i < e; i += SEG_LANES) {
+        uint32_t idx = sv[i];
+        double d0 = (double)tx[idx] - org[0], d1 = (double)ty[idx] - org[1], d2 = (double)tz[idx] - org[2];
+        a[0] += d0; a[1] += d1; a[2] += d2;
+        a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+        a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+    }
+#pragma unroll
+    for (int o = SEG_LANES / 2; o >= 1; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
+    if (!act || l != 0) return;
+
+    const int32_t nb = (int32_t)(e - s);
+    double mu[3] = {a[0] / nb, a[1] / nb, a[2] / nb};
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    if (nb > 1) {   // ComputeMeanAndCov: sample covariance over (n-1)
+        double dn = (double)(nb - 1);
+        cv[0] = (a[3] - a[0] * mu[0]) / dn; cv[1] = (a[4] - a[0] * mu[1]) / dn; cv[2] = (a[5] - a[0] * mu[2]) / dn;
+        cv[3] = (a[6] - a[1] * mu[1]) / dn; cv[4] = (a[7] - a[1] * mu[2]) / dn; cv[5] = (a[8] - a[2] * mu[2]) / dn;
+    }
+    // find-or-insert (capacity was sized by the host so that the load factor stays <= 1/2)
+    uint64_t slot = ndt_mix64((uint64_t)key) & mask;
+    bool fresh = false;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&slots[slot].key, (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
+        if ((int64_t)prev == NDT_KEY_EMPTY) { fresh = true; break; }
+        if ((int64_t)prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    VoxSlot* sl = &slots[slot];
+    double* mp = mean + slot * 3;
+    double* cp = cov + slot * 6;
+    int32_t ntot = nb;
+    if (fresh) {
+        atomicAdd(n_vox, 1);
+    } else {        // UpdateMeanAndCov (math_utils.h:87-98)
+        double hm = (double)sl->n, cn = (double)nb, tot = hm + cn;
+        double nm[3], dh[3], dc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            nm[j] = (hm * mp[j] + cn * mu[j]) / tot;
+            dh[j] = mp[j] - nm[j];
+            dc[j] = mu[j] - nm[j];
+        }
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = r; c < 3; ++c, ++t) cv[t] = (hm * (cp[t] + dh[r] * dh[c]) + cn * (cv[t] + dc[r] * dc[c])) / tot;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu[j] = nm[j];
+        ntot = sl->n + nb;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mp[j] = mu[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cp[j] = cv[j];
+    finalize_slot(sl, ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+}
+
+// ------------------------------------------------------------------ rehash (capacity growth)
+
+__global__ void k_rehash(const VoxSlot* os, const double* om, const double* oc, size_t ocap, VoxSlot* ns, double* nm, double* nc, uint64_t nmask) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ocap) return;
+    VoxSlot v = os[i];
+    if (v.key == NDT_KEY_EMPTY) return;
+    uint64_t slot = ndt_mix64((uint64_t)v.key) & nmask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&ns[slot].key, (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)v.key);
+        if ((int64_t)prev == NDT_KEY_EMPTY) break;
+        slot = (slot + 1) & nmask;
+    }
+    VoxSlot* d = &ns[slot];
+    d->valid = v.valid; d->i22 = v.i22; d->off[0] = v.off[0]; d->off[1] = v.off[1]; d->off[2] = v.off[2];
+    d->i00 = v.i00; d->i01 = v.i01; d->i02 = v.i02; d->i11 = v.i11; d->i12 = v.i12; d->n = v.n;
+    for (int j = 0; j < 3; ++j) nm[slot * 3 + j] = om[i * 3 + j];
+    for (int j = 0; j < 6; ++j) nc[slot * 6 + j] = oc[i * 6 + j];
+}
+
+static size_t pow2_at_least(size_t v) { size_t c = 1024; while (c < v) c <<= 1; return c; }
+
+static int map_reserve(VoxelMap& m, size_t want_voxels, hipStream_t s, std::string& err) {
+    size_t need = pow2_at_least(want_voxels * 2);       // load factor <= 1/2
+    if (m.cap >= need) return NDT_OK;
+    size_t ncap = pow2_at_least(want_voxels * 4);        // grow with headroom
+    VoxelMap nm;
+    HIP_TRY(map_alloc(nm, ncap, s));
+    if (m.cap) {
+        k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, nm.slots, nm.mean, nm.cov, ncap - 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(nm.d_n_vox, m.d_n_vox, 4, hipMemcpyDeviceToDevice, s));
+        nm.n_vox = m.n_vox;
+        HIP_TRY(hipStreamSynchronize(s));
+        map_free(m);
+    }
+    m = nm;
+    return NDT_OK;
+}
+
+static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; return b; }
+
+int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, size_t n, size_t stride,
+                     const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
+    if (passes) *passes = 0;
+    if (n == 0) return map_reserve(m, 1, s, err);
+    if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
+    HIP_TRY(w.raw.ensure(n * stride));
+    HIP_TRY(hipMemcpyAsync(w.raw.p, pts, n * stride, hipMemcpyDefault, s));
+    HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
+    HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.keys_b.ensure(n * 8));
+    HIP_TRY(w.vals_a.ensure(n * 4)); HIP_TRY(w.vals_b.ensure(n * 4));
+    HIP_TRY(w.misc.ensure(256));
+    int32_t init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
+    HIP_TRY(hipMemcpyAsync(w.misc.p, init, sizeof init, hipMemcpyHostToDevice, s));
+    double* dRt = (double*)((char*)w.misc.p + 64);
+    if (R) {
+        double Rt[12];
+        for (int i = 0; i < 9; ++i) Rt[i] = R[i];
+        for (int i = 0; i < 3; ++i) Rt[9 + i] = t[i];
+        HIP_TRY(hipMemcpyAsync(dRt, Rt, sizeof Rt, hipMemcpyHostToDevice, s));
+    }
+    const unsigned nb256 = (unsigned)((n + 255) / 256);
+    k_target_keys<<<nb256, 256, 0, s>>>((const unsigned char*)w.raw.p, n, stride, R ? 1 : 0, dRt, cfg.kp, w.tx.as<float>(), w.ty.as<float>(),
+                                        w.tz.as<float>(), w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.misc.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    int32_t misc[8];
+    HIP_TRY(hipMemcpyAsync(misc, w.misc.p, sizeof misc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const size_t n_valid = (size_t)misc[6];
+    if (n_valid == 0) return map_reserve(m, 1, s, err);
+
+    SortKeyMap km;
+    int total_bits = 0;
+    for (int j = 0; j < 3; ++j) {
+        km.mn[j] = misc[j];
+        km.bits[j] = bits_for((int64_t)misc[3 + j] - misc[j] + 1);
+        total_bits += km.bits[j];
+    }
+    k_sort_keys<<<nb256, 256, 0, s>>>(w.keys_a.as<int64_t>(), n, km);
+    HIP_TRY(hipGetLastError());
+
+    // LSD radix sort over the bits that exist
+    const int P = std::max(1, (total_bits + 7) / 8);
+    const unsigned nblk = (unsigned)((n + RS_TILE - 1) / RS_TILE);
+    const size_t nh = (size_t)256 * nblk;
+    HIP_TRY(w.hist.ensure(nh * 4));
+    HIP_TRY(w.scan_tmp.ensure(((std::max(nh, n) + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
+    uint64_t* ka = w.keys_a.as<uint64_t>(); uint64_t* kb = w.keys_b.as<uint64_t>();
+    uint32_t* va = w.vals_a.as<uint32_t>(); uint32_t* vb = w.vals_b.as<uint32_t>();
+    for (int p = 0; p < P; ++p) {
+        k_radix_hist<<<nblk, RS_THREADS, 0, s>>>(ka, n, 8 * p, w.hist.as<uint32_t>(), nblk);
+        exclusive_scan_u32(w.hist.as<uint32_t>(), w.hist.as<uint32_t>(), nh, w.scan_tmp.as<uint32_t>(), nullptr, s);
+        k_radix_scatter<<<nblk, RS_THREADS, 0, s>>>(ka, va, n, 8 * p, w.hist.as<uint32_t>(), nblk, kb, vb);
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+    HIP_TRY(hipGetLastError());
+    if (passes) *passes = P;
+
+    // segments over the valid prefix
+    HIP_TRY(w.flags.ensure(n_valid * 4)); HIP_TRY(w.segid.ensure(n_valid * 4));
+    const unsigned nbv = (unsigned)((n_valid + 255) / 256);
+    k_heads<<<nbv, 256, 0, s>>>(ka, n_valid, w.flags.as<uint32_t>());
+    uint32_t* d_nseg = (uint32_t*)(w.misc.as<int32_t>() + 7);
+    exclusive_scan_u32(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.scan_tmp.as<uint32_t>(), d_nseg, s);
+    uint32_t nseg = 0;
+    HIP_TRY(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(w.seg_start.ensure(((size_t)nseg + 1) * 4));
+    k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+
+    int rc = map_reserve(m, (size_t)m.n_vox + nseg, s, err);
+    if (rc != NDT_OK) return rc;
+    const unsigned nbs = (unsigned)(((size_t)nseg * SEG_LANES + 255) / 256);
+    k_segment_merge<<<nbs, 256, 0, s>>>(ka, va, w.seg_start.as<uint32_t>(), nseg, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), km, cfg,
+                                        m.slots, m.mean, m.cov, (uint64_t)(m.cap - 1), m.d_n_vox);
+    HIP_TRY(hipGetLastError());
+    int32_t nv = 0;
+    HIP_TRY(hipMemcpyAsync(&nv, m.d_n_vox, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m.n_vox = nv;
+    return NDT_OK;
+}
+
+// ------------------------------------------------------------------ export (parity checks)
+
+__global__ void k_export(const VoxSlot* slots, const double* mean, const double* cov, size_t cap, uint32_t* counter, VoxSlot* oslots,
+                         double* omean, double* ocov) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    VoxSlot v = slots[i];
+    if (v.key == NDT_KEY_EMPTY) return;
+    uint32_t o = atomicAdd(counter, 1u);
+    oslots[o] = v;
+    for (int j = 0; j < 3; ++j) omean[(size_t)o * 3 + j] = mean[i * 3 + j];
+    for (int j = 0; j < 6; ++j) ocov[(size_t)o * 6 + j] = cov[i * 6 + j];
+}
+
+int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& keys, std::vector<int32_t>& counts,
+               std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
+               std::vector<uint8_t>& valid, hipStream_t s, std::string& err) {
+    const size_t nv = (size_t)m.n_vox;
+    keys.assign(nv, 0); counts.assign(nv, 0); mean.assign(nv * 3, 0); cov.assign(nv * 9, 0); info.assign(nv * 9, 0); valid.assign(nv, 0);
+    if (!nv) return NDT_OK;
+    DevBuf dcnt, dsl, dm, dc;
+    HIP_TRY(dcnt.ensure(4)); HIP_TRY(dsl.ensure(nv * sizeof(VoxSlot))); HIP_TRY(dm.ensure(nv * 24)); HIP_TRY(dc.ensure(nv * 48));
+    HIP_TRY(hipMemsetAsync(dcnt.p, 0, 4, s));
+    k_export<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, dcnt.as<uint32_t>(), dsl.as<VoxSlot>(), dm.as<double>(), dc.as<double>());
+    HIP_TRY(hipGetLastError());
+    std::vector<VoxSlot> hs(nv);
+    std::vector<double> hm(nv * 3), hc(nv * 6);
+    HIP_TRY(hipMemcpyAsync(hs.data(), dsl.p, nv * sizeof(VoxSlot), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hm.data(), dm.p, nv * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hc.data(), dc.p, nv * 48, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    dcnt.release(); dsl.release(); dm.release(); dc.release();
+    std::vector<size_t> ord(nv);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return hs[a].key < hs[b].key; });
+    static const int U[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (size_t o = 0; o < nv; ++o) {
+        const size_t i = ord[o];
+        const VoxSlot& v = hs[i];
+        int32_t c[3];
+        ndt_unpack(v.key, c[0], c[1], c[2]);
+        keys[o] = v.key; counts[o] = v.n; valid[o] = (uint8_t)v.valid;
+        const double inf6[6] = {v.i00, v.i01, v.i02, v.i11, v.i12, v.i22};
+        for (int r = 0; r < 3; ++r) {
+            mean[o * 3 + r] = (double)c[r] * kp.res_d + hm[i * 3 + r];
+            for (int cc = 0; cc < 3; ++cc) {
+                cov[o * 9 + r * 3 + cc] = hc[i * 6 + U[r][cc]];
+                info[o * 9 + r * 3 + cc] = inf6[U[r][cc]];
+            }
+        }
+    }
+    return NDT_OK;
+}
