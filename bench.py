@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — NDT scan-matching throughput on MI355X (BASELINE.json metric).
+
+Workload at N=1 (configs[2], the configuration the metric is quoted on): one HDL-64-shaped scan
+(~120k points) aligned against a GPU-resident voxel map built from a 2M-point keyframe map, NEARBY7,
+1.0 m voxels.  One step = one full `ndt_align` of the resident scan from the perturbed ("IMU-predicted")
+pose, with a fixed number of Gauss-Newton iterations (eps = 0, so no work can be skipped).
+value = source points x Gauss-Newton iterations per second, whole job.
+
+N>1 (`torch.distributed.run`, one process per GPU): offline replay — every rank holds a replica of the
+map and aligns its own scans; no data-path collective; weak scaling.  `--mode sharded` instead shards one
+dense source cloud over the ranks with an RCCL all-reduce of the 29 H/b/chi2/n terms per iteration
+(configs[3]); it is also run as a secondary measurement after the main one when N>1.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_point(k, h):
+    """B_res = 12 (xyz) + 8 k (key slot per probe) + 40 h (payload per valid hit)."""
+    return 12.0 + 8.0 * k + 40.0 * h
+
+
+def load_workload(index, rank, world, dist, small):
+    """configs[index] inputs; generated once (rank 0) and cached under /tmp for the other ranks / later runs."""
+    from lio_slam_amd import synth
+    path = f"/tmp/ndt_bench_c{index}{'_small' if small else ''}.npz"
+    if rank == 0 and not os.path.exists(path):
+        c = synth.make_config(index, small=small)
+        extra = {}
+        if index == 2:   # a few more scans along the trajectory: keyframes to merge, replay scans for other ranks
+            rng = np.random.Generator(np.random.PCG64(synth.seed_for(index) + 1000))
+            n = len(c["poses"])
+            for j in range(8):
+                T = c["poses"][(n // 2 + 1 + j) % n].copy()
+                T[:3, 3] += rng.uniform(-0.2, 0.2, 3) * [1, 1, 0]
+                extra[f"scan{j}"] = synth.scan(c["scene"], "hdl64", T, rng)
+                extra[f"T{j}"] = T
+                extra[f"guess{j}"] = T @ synth.perturbation(rng)
+        tmp = path + f".{os.getpid()}.npz"
+        np.savez(tmp, map=c["map"], scan=c["scan"], T_true=c["T_true"], guess=c["guess"], **extra)
+        os.replace(tmp, path)
+    if world > 1:
+        dist.barrier()
+    return dict(np.load(path))
+
+
+def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
+    """The CPU oracle (a port of the same algorithm, oracle/ndt_oracle.c) on this box's host cores."""
+    from oracle.oracle import Oracle
+    out = {}
+    o = Oracle(nearby=nearby, max_iterations=iters, eps=0.0, final_eval=0)
+    t0 = time.perf_counter(); o.set_target(w["map"]); build_s = time.perf_counter() - t0
+    o.set_source(w["scan"])
+    n = o.source_size()
+    for name, threads in (("cpu_baseline", 1), ("cpu_baseline_mt", min(16, os.cpu_count() or 1))):
+        o.set_threads(threads)
+        o.align(w["guess"])                      # warm
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            o.align(w["guess"]); reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or reps >= 200:
+                break
+        out[name] = {"value": n * iters * reps / el, "unit": "source-points*iters/s", "cores": threads, "kind": "port",
+                     "sample": f"{reps} aligns x {iters} GN iterations of the same {n}-pt scan vs 2M-pt map "
+                               f"({el:.1f} s of CPU work)", "scans_per_s": reps / el}
+    out["cpu_baseline"]["map_build_s"] = build_s
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=10, help="Gauss-Newton iterations per align (fixed)")
+    ap.add_argument("--nearby", type=int, default=7)
+    ap.add_argument("--mode", choices=["replay", "sharded"], default="replay")
+    ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        # rendezvous / barriers / timing reductions on CPU tensors (gloo); the data-path collective, where the
+        # mode has one, is RCCL inside libndt_mi355.so on the handle's own stream
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lio_slam_amd as la
+
+    w = load_workload(2, rank, world, dist, a.small)
+    ndt = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+
+    t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = min(build_ms, 1e3 * (time.perf_counter() - t0))
+    n_vox = ndt.num_voxels()
+    merge_ms = []
+    for j in range(2):       # incremental keyframe merge (configs[2]): two keyframes into the resident map
+        t0 = time.perf_counter(); ndt.add_target(w[f"scan{j}"], w[f"T{j}"]); ndt.synchronize()
+        merge_ms.append(1e3 * (time.perf_counter() - t0))
+
+    if a.mode == "sharded":
+        scan_all, guess = w["scan"], w["guess"]
+        lo, hi = len(scan_all) * rank // world, len(scan_all) * (rank + 1) // world
+        scan = scan_all[lo:hi]
+        if world > 1:
+            ids = [la.NDT.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ndt.comm_init(rank, world, ids[0])
+        total_pts = len(scan_all)
+    else:
+        j = rank % 8
+        scan, guess = (w["scan"], w["guess"]) if rank == 0 else (w[f"scan{j}"], w[f"guess{j}"])
+        total_pts = None
+    ndt.set_source(scan)                      # resident in HBM before the timed region
+    n_src = ndt.source_size()
+
+    def barrier():
+        ndt.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        r = ndt.align(guess)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = ndt.align(guess)
+    ndt.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t[0])
+        cnt = torch.tensor([float(n_src)], dtype=torch.float64); dist.all_reduce(cnt); pts_all = float(cnt[0])
+    else:
+        pts_all = float(n_src)
+    assert r["iterations"] == a.iters, r
+    units = (float(total_pts) if a.mode == "sharded" else pts_all) * a.iters * a.steps
+    value = units / el
+
+    # roofline of the dominant kernel (k_residual): HIP events on the handle's stream around every launch,
+    # over a repeat of the same steps (kept out of the timed region so the events do not perturb `value`)
+    ndt.profile(True)
+    for _ in range(a.steps):
+        ndt.align(guess)
+    pr = ndt.profile_read()
+    ndt.profile(False)
+    k_us = pr["residual_us"] / max(1, pr["launches"])
+    h = pr["hits_per_point"]
+    bpp = algorithmic_bytes_per_point(a.nearby, h)
+    achieved = n_src * bpp / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
+
+    out = {
+        "metric": "NDT source-points*iters/sec (120k-pt scan vs 2M-pt map)", "value": value, "unit": "source-points*iters/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+        "higher_is_better": True, "scaling": "weak" if a.mode == "replay" else "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("configs[2]: HDL-64-shaped scan vs GPU-resident voxel map of a 2M-pt keyframe map"
+                                + (" (SMALL 200k-pt map: not a valid number)" if a.small else "")),
+                   "mode": a.mode, "source_points_per_rank": int(n_src), "map_points": int(len(w["map"])),
+                   "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0, "gn_iterations_per_align": a.iters,
+                   "parallelism": f"{a.mode}{world}"},
+        "scans_per_s": a.steps * (world if a.mode == "replay" else 1) / el,
+        "map_build_ms": build_ms, "keyframe_merge_ms": merge_ms,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_residual<7>" if a.nearby == 7 else "k_residual<1>",
+                     "kernel_avg_us": k_us, "launches": pr["launches"], "bytes_per_point": bpp, "hits_per_point": h,
+                     "points_per_launch": int(n_src), "timing": "hipEvent pairs on the engine stream, per launch"},
+        "final_pose_error_m": float(np.linalg.norm((np.linalg.inv(w["T_true"]) @ r["T"])[:3, 3])) if rank == 0 and a.mode == "replay" else None,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out.update(time_cpu_baseline(w, a.iters, a.nearby))
+        out["gpu_over_cpu1"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ndt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
