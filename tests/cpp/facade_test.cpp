@@ -1,0 +1,60 @@
+// Drives the C++ facade the way src/slam/src/process.cc drives its PCL member (lines 373-376, 78, 87, 94-95, 147),
+// on clouds of the reference's own 32-byte point record.  Input: a binary file written by tests/test_gpu_facade.py;
+// output: pose, Hessian, iteration count as text.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "ndt_mi355.hpp"
+
+struct alignas(16) Point {   // slam_czc::Point (src/slam/include/utility.h:54-61)
+    float x, y, z, w;
+    float intensity, time;
+    std::uint16_t ring;
+};
+static_assert(sizeof(Point) == 32, "layout of slam_czc::Point");
+using PointCloud = std::vector<Point>;
+
+static std::shared_ptr<PointCloud> read_cloud(FILE* f) {
+    std::uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1) exit(3);
+    auto c = std::make_shared<PointCloud>(n);
+    for (auto& p : *c) {
+        float v[3];
+        if (fread(v, 4, 3, f) != 3) exit(3);
+        p = Point{v[0], v[1], v[2], 1.f, 0.f, 0.f, 0};
+    }
+    return c;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    auto pc_key = read_cloud(f), keyframe = read_cloud(f), scan = read_cloud(f);
+    float guess[16];
+    double Tk[16];
+    if (fread(guess, 4, 16, f) != 16 || fread(Tk, 8, 16, f) != 16) return 3;
+    fclose(f);
+
+    ndt_mi355::NormalDistributionsTransform<Point, Point> ndt_;
+    ndt_.setResolution(1.0);             // process.cc:373-376
+    ndt_.setMaximumIterations(35);
+    ndt_.setTransformationEpsilon(0.01);
+    ndt_.setStepSize(0.1);
+    ndt_.setInputTarget(pc_key);         // process.cc:78
+    ndt_.addTargetCloud(*keyframe, Tk);  // process.cc:134-147, incrementally
+    ndt_.setInputSource(scan);           // process.cc:87
+    PointCloud output;
+    ndt_.align(output, guess);           // process.cc:94   (Matrix4f guess)
+    auto T = ndt_.getFinalTransformation();   // process.cc:95
+    auto H = ndt_.getHessian();
+    printf("status %d converged %d iterations %d\n", ndt_.status(), (int)ndt_.hasConverged(), ndt_.getFinalNumIteration());
+    for (double v : T) printf("%.17g ", v);
+    printf("\n");
+    for (double v : H) printf("%.17g ", v);
+    printf("\n");
+    return 0;
+}

@@ -1,0 +1,40 @@
+"""The C++ facade (include/ndt_mi355.hpp) driven like process.cc drives PCL, checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "lio-slam_amd", "facade_test")
+
+
+def test_cpp_facade_matches_oracle(tmp_path):
+    from lio_slam_amd import synth
+    from oracle.oracle import Oracle
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    c = synth.make_config(1, small=True)
+    Tk = c["poses"][3]
+    kf = synth.scan(c["scene"], "vlp16", Tk, np.random.default_rng(3))
+    guess32 = c["guess"].astype(np.float32)          # the reference's guess is a Matrix4f (utility.cc:34)
+    path = tmp_path / "in.bin"
+    with open(path, "wb") as f:
+        for cloud in (c["map"], kf, c["scan"]):
+            f.write(struct.pack("<Q", len(cloud))); f.write(np.ascontiguousarray(cloud, np.float32).tobytes())
+        f.write(np.ascontiguousarray(guess32.T).tobytes()); f.write(np.ascontiguousarray(Tk.T).tobytes())
+    out = subprocess.run([EXE, str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    st = lines[0].split()
+    T = np.array(lines[1].split(), float).reshape(4, 4).T
+    H = np.array(lines[2].split(), float).reshape(6, 6)
+    o = Oracle()
+    o.set_target(c["map"]); o.add_target(kf, Tk); o.set_source(c["scan"])
+    r = o.align(guess32.astype(np.float64))
+    assert int(st[1]) == 0 and int(st[3]) == int(r["converged"]) and int(st[5]) == r["iterations"]
+    dt, dr = pose_error(T, r["T"])
+    assert dt < 1e-4 and dr < 1e-5
+    assert rel_err(H, r["H"]) < 1e-5
