@@ -172,6 +172,10 @@ int ndt_profile(ndt_handle* h, int enable);
 int ndt_profile_read(ndt_handle* h, double* residual_kernel_us, int64_t* residual_launches,
                      double* mean_hits_per_point);
 
+/* Mean duration of the residual kernel alone: `reps` back-to-back launches at pose T between two HIP events on
+ * the handle's stream (what bench.py's roofline uses; agrees with rocprofv3 --kernel-trace). */
+int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_per_launch);
+
 /* Blocks until all work queued on the handle's stream has finished. */
 int ndt_synchronize(ndt_handle* h);
 

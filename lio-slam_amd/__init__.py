@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_comm_unique_id",
-    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_synchronize",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
 
@@ -97,6 +97,7 @@ def lib():
     L.ndt_comm_destroy.argtypes = [vp]
     L.ndt_profile.argtypes = [vp, C.c_int]
     L.ndt_profile_read.argtypes = [vp, vp, vp, vp]
+    L.ndt_time_residual.argtypes = [vp, vp, C.c_int, vp]
     L.ndt_synchronize.argtypes = [vp]
     L.ndt_last_error.restype = C.c_char_p
     L.ndt_last_error.argtypes = [vp]
@@ -238,6 +239,12 @@ class NDT:
         us = C.c_double(); n = C.c_int64(); hp = C.c_double()
         self._chk(lib().ndt_profile_read(self._h, C.addressof(us), C.addressof(n), C.addressof(hp)))
         return dict(residual_us=us.value, launches=n.value, hits_per_point=hp.value)
+
+    def time_residual(self, T, reps=200):
+        """Mean microseconds of one residual-kernel launch at pose T (HIP events around `reps` launches)."""
+        t = _T(T); us = C.c_double()
+        self._chk(lib().ndt_time_residual(self._h, t.ctypes.data, int(reps), C.addressof(us)))
+        return us.value
 
     def synchronize(self): self._chk(lib().ndt_synchronize(self._h))
 

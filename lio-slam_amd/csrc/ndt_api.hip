@@ -241,7 +241,7 @@ static int queue_pass(ndt_handle* h, int do_solve, int force, int64_t* keys_out,
     const SolveParams sp = solve_params(h);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) { e0 = next_event(h); e1 = next_event(h); if (e0) (void)hipEventRecord(e0, h->stream); }
-    launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.slots, (uint64_t)(h->map.cap - 1),
+    launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
                     h->d_state, ep, h->partials.as<double>(), grid, force, keys_out, mask_out, h->stream);
     if (h->prof && e1) (void)hipEventRecord(e1, h->stream);
     if (h->comm) {
@@ -419,6 +419,33 @@ int ndt_profile_read(ndt_handle* h, double* us, int64_t* launches, double* hits_
     if (us) *us = h->prof_us;
     if (launches) *launches = h->prof_launches;
     if (hits_per_point) *hits_per_point = h->prof_pts > 0 ? h->prof_hits / h->prof_pts : 0.0;
+    return NDT_OK;
+}
+
+int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_per_launch) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!T || reps < 1 || !us_per_launch) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
+    state_from_T(h->h_state, T);
+    H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    const int grid = residual_grid(h->n_src);
+    const EvalParams ep = eval_params(h);
+    auto pass = [&]() {
+        launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
+                        (uint32_t)(h->map.cap - 1), h->d_state, ep, h->partials.as<double>(), grid, 1, nullptr, nullptr, h->stream);
+    };
+    for (int i = 0; i < 3; ++i) pass();   // warm
+    H_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) pass();
+    H_TRY(hipEventRecord(e1, h->stream));
+    H_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    H_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_per_launch = 1e3 * (double)ms / reps;
     return NDT_OK;
 }
 

@@ -79,6 +79,23 @@ __host__ __device__ inline uint64_t ndt_mix64(uint64_t x) {
     x ^= x >> 33;
     return x;
 }
+// Table hash: per-axis multiplicative spatial hash (a face neighbour's hash is one add and two xors away from
+// the centre's) followed by one 32-bit avalanche round.  Capacity is a power of two <= 2^31.
+#define NDT_HP0 73856093u
+#define NDT_HP1 19349669u
+#define NDT_HP2 83492791u
+__host__ __device__ inline uint32_t ndt_hash_fin(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13;
+    return h;
+}
+__host__ __device__ inline uint32_t ndt_hash_cell(int32_t ix, int32_t iy, int32_t iz) {
+    return ndt_hash_fin(((uint32_t)ix * NDT_HP0) ^ ((uint32_t)iy * NDT_HP1) ^ ((uint32_t)iz * NDT_HP2));
+}
+__host__ __device__ inline uint32_t ndt_hash_key(int64_t k) {
+    int32_t x, y, z;
+    ndt_unpack(k, x, y, z);
+    return ndt_hash_cell(x, y, z);
+}
 __device__ inline bool ndt_in_range(double v) { return v >= -(double)NDT_KEY_BIAS && v < (double)NDT_KEY_BIAS; }
 
 // Arithmetic contract with the oracle: plain float64 multiplies and adds in this order,

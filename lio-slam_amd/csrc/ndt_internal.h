@@ -26,6 +26,8 @@ struct DevBuf {   // grow-only device allocation
 
 struct VoxelMap {          // the GPU-resident voxel hash
     VoxSlot* slots = nullptr;
+    int64_t* keys = nullptr;   // [cap+4] dense copy of the slot keys (what a probe reads: 8 B per slot);
+                               // keys[cap..cap+3] mirror keys[0..3] so a 32-byte four-key read never wraps
     double* mean = nullptr;    // [cap*3] running mean offset from the voxel origin
     double* cov = nullptr;     // [cap*6] running covariance, xx xy xz yy yz zz
     size_t cap = 0;            // power of two (0 = no map)
@@ -66,7 +68,7 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 
 // ---- ndt_residual.hip
 int residual_grid(size_t n);
-void launch_residual(const float* x, const float* y, const float* z, int n, const VoxSlot* slots, uint64_t mask,
+void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, hipStream_t s);
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve,

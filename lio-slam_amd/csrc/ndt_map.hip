@@ -17,8 +17,9 @@
 
 // ------------------------------------------------------------------ table init / alloc
 
-__global__ void k_init_slots(VoxSlot* s, size_t cap) {
+__global__ void k_init_slots(VoxSlot* s, int64_t* keys, size_t cap) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap + 4) keys[i] = NDT_KEY_EMPTY;
     if (i >= cap) return;
     VoxSlot v = {};
     v.key = NDT_KEY_EMPTY;
@@ -28,17 +29,19 @@ __global__ void k_init_slots(VoxSlot* s, size_t cap) {
 hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     hipError_t e;
     if ((e = hipMalloc((void**)&m.slots, cap * sizeof(VoxSlot))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&m.keys, (cap + 4) * sizeof(int64_t))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.mean, cap * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.cov, cap * 6 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.d_n_vox, 256)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(m.d_n_vox, 0, 256, s)) != hipSuccess) return e;
     m.cap = cap;
     m.n_vox = 0;
-    k_init_slots<<<(unsigned)((cap + 255) / 256), 256, 0, s>>>(m.slots, cap);
+    k_init_slots<<<(unsigned)((cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, cap);
     return hipGetLastError();
 }
 void map_free(VoxelMap& m) {
     if (m.slots) (void)hipFree(m.slots);
+    if (m.keys) (void)hipFree(m.keys);
     if (m.mean) (void)hipFree(m.mean);
     if (m.cov) (void)hipFree(m.cov);
     if (m.d_n_vox) (void)hipFree(m.d_n_vox);
@@ -328,7 +331,7 @@ __device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3],
 // xor-tree over the 8 lanes, then lane 0 claims / finds the hash slot, merges and finalises.
 __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* sv, const uint32_t* seg_start, uint32_t nseg,
                                                        const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
-                                                       VoxSlot* slots, double* mean, double* cov, uint64_t mask, int32_t* n_vox) {
+                                                       VoxSlot* slots, int64_t* keys, double* mean, double* cov, uint64_t mask, int32_t* n_vox) {
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     bool act = g < nseg;
@@ -366,10 +369,10 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
         cv[3] = (a[6] - a[1] * mu[1]) / dn; cv[4] = (a[7] - a[1] * mu[2]) / dn; cv[5] = (a[8] - a[2] * mu[2]) / dn;
     }
     // find-or-insert (capacity was sized by the host so that the load factor stays <= 1/2)
-    uint64_t slot = ndt_mix64((uint64_t)key) & mask;
+    uint64_t slot = ndt_hash_key(key) & mask;
     bool fresh = false;
     for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&slots[slot].key, (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
         if ((int64_t)prev == NDT_KEY_EMPTY) { fresh = true; break; }
         if ((int64_t)prev == key) break;
         slot = (slot + 1) & mask;
@@ -380,6 +383,8 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     int32_t ntot = nb;
     if (fresh) {
         atomicAdd(n_vox, 1);
+        sl->key = key;
+        if (slot < 4) keys[mask + 1 + slot] = key;   // mirror entries
     } else {        // UpdateMeanAndCov (math_utils.h:87-98)
         double hm = (double)sl->n, cn = (double)nb, tot = hm + cn;
         double nm[3], dh[3], dc[3];
@@ -407,18 +412,20 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
 
 // ------------------------------------------------------------------ rehash (capacity growth)
 
-__global__ void k_rehash(const VoxSlot* os, const double* om, const double* oc, size_t ocap, VoxSlot* ns, double* nm, double* nc, uint64_t nmask) {
+__global__ void k_rehash(const VoxSlot* os, const double* om, const double* oc, size_t ocap, VoxSlot* ns, int64_t* nk, double* nm, double* nc, uint64_t nmask) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ocap) return;
     VoxSlot v = os[i];
     if (v.key == NDT_KEY_EMPTY) return;
-    uint64_t slot = ndt_mix64((uint64_t)v.key) & nmask;
+    uint64_t slot = ndt_hash_key(v.key) & nmask;
     for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&ns[slot].key, (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)v.key);
+        unsigned long long prev = atomicCAS((unsigned long long*)&nk[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)v.key);
         if ((int64_t)prev == NDT_KEY_EMPTY) break;
         slot = (slot + 1) & nmask;
     }
+    if (slot < 4) nk[nmask + 1 + slot] = v.key;
     VoxSlot* d = &ns[slot];
+    d->key = v.key;
     d->valid = v.valid; d->i22 = v.i22; d->off[0] = v.off[0]; d->off[1] = v.off[1]; d->off[2] = v.off[2];
     d->i00 = v.i00; d->i01 = v.i01; d->i02 = v.i02; d->i11 = v.i11; d->i12 = v.i12; d->n = v.n;
     for (int j = 0; j < 3; ++j) nm[slot * 3 + j] = om[i * 3 + j];
@@ -434,7 +441,7 @@ static int map_reserve(VoxelMap& m, size_t want_voxels, hipStream_t s, std::stri
     VoxelMap nm;
     HIP_TRY(map_alloc(nm, ncap, s));
     if (m.cap) {
-        k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, nm.slots, nm.mean, nm.cov, ncap - 1);
+        k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.mean, nm.cov, ncap - 1);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(nm.d_n_vox, m.d_n_vox, 4, hipMemcpyDeviceToDevice, s));
         nm.n_vox = m.n_vox;
@@ -521,7 +528,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     if (rc != NDT_OK) return rc;
     const unsigned nbs = (unsigned)(((size_t)nseg * SEG_LANES + 255) / 256);
     k_segment_merge<<<nbs, 256, 0, s>>>(ka, va, w.seg_start.as<uint32_t>(), nseg, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), km, cfg,
-                                        m.slots, m.mean, m.cov, (uint64_t)(m.cap - 1), m.d_n_vox);
+                                        m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), m.d_n_vox);
     HIP_TRY(hipGetLastError());
     int32_t nv = 0;
     HIP_TRY(hipMemcpyAsync(&nv, m.d_n_vox, 4, hipMemcpyDeviceToHost, s));

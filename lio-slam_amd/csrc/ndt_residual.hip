@@ -5,135 +5,239 @@
 // k_residual: one source point per lane.  q' = R q + t in float64, cell = rule(q'/res), K hash probes
 // (centre + 6 face neighbours), Mahalanobis residual against the 40-byte voxel payload, chi^2 gate.  The
 // per-point sums S = sum Sigma^-1 and g = sum Sigma^-1 e are folded once per point through the 3x6
-// Jacobian J = [-R hat(q) | I] into 21 + 6 accumulators per lane; lanes -> wave (shuffle tree) -> block
-// (LDS) -> one 32-double row per block in HBM.  k_reduce_solve adds the rows in a fixed order and takes
-// the Gauss-Newton step on the device, so an iteration never returns to the host.
+// Jacobian J = [-R hat(q) | I] into 21 + 6 accumulators per lane.
+//   memory schedule : all K key reads (16 B = slot s and s+1 of the dense key array) are issued before any is
+//                     used; then all payload reads of the slots that matched; chains longer than two slots
+//                     are finished for all K probes together in one wave-uniform loop.
+//   reduction       : lanes -> wave by a butterfly reduce-scatter (32 double exchanges instead of 30 x 6),
+//                     wave -> block through LDS, one 32-double row per block in HBM; every order is fixed.
+// k_reduce_solve adds the rows in a fixed order and takes the Gauss-Newton step on the device, so an iteration
+// never returns to the host.
 // Bound: HBM/L2 gather (12 + 8K + 40h algorithmic bytes per point); no MFMA.
 #include "ndt_internal.h"
 
-static const __device__ int NB7[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-
 #define RES_THREADS 256
-#define NACC 30   // 21 H + 6 b + chi2 + n_eff + hits
+#define SLOT_NONE 0xFFFFFFFFu
 
+struct Pose { double R[9]; double t[3]; };
+
+// neighbour offsets: centre, -x, +x, -y, +y, -z, +z  (same order as the oracle)
+struct __attribute__((aligned(8))) Key2 { int64_t x, y; };   // two adjacent entries of the dense key array
+
+__device__ inline bool cell_ok(int32_t v) { return (uint32_t)(v + NDT_KEY_BIAS) < (uint32_t)(2 * NDT_KEY_BIAS); }
+
+// Accumulates one source point into acc[0..29].  Returns the hit mask; *cell_key gets the centre key (or EMPTY).
 template <int K>
-__global__ __launch_bounds__(RES_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
-                                                          const float* __restrict__ zs, int n, const VoxSlot* __restrict__ slots,
-                                                          uint64_t mask, const GnState* __restrict__ st, EvalParams ep,
-                                                          double* __restrict__ partials, int force, int64_t* keys_out, uint8_t* mask_out) {
-    if (!force && st->done) return;
-    double R[9], t[3];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) R[j] = st->R[j];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) t[j] = st->t[j];
+__device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
+                                                const VoxSlot* __restrict__ slots, uint32_t mask, const EvalParams& ep,
+                                                double* acc, int64_t* cell_key) {
+    double q[3];
+    ndt_xform(P.R, P.t, xf, yf, zf, q);
+    int32_t c[3];
+    if (!ndt_source_cell(ep.kp, q, c)) { *cell_key = NDT_KEY_EMPTY; return 0; }   // non-finite / out of key range
+    const int64_t ckey = ndt_pack(c[0], c[1], c[2]);
+    *cell_key = ckey;
+    const uint32_t hx = (uint32_t)c[0] * NDT_HP0, hy = (uint32_t)c[1] * NDT_HP1, hz = (uint32_t)c[2] * NDT_HP2;
 
-    double acc[NACC];
+    // ---- round 1: four keys per probe (two 16-byte reads), all probes in flight together
+    int64_t want[K];
+    uint32_t s0[K];
+    Key2 ka[K], kb[K];
+    bool live[K];
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
-
-    for (int i = blockIdx.x * RES_THREADS + threadIdx.x; i < n; i += gridDim.x * RES_THREADS) {
-        const float xf = xs[i], yf = ys[i], zf = zs[i];
-        double q[3];
-        ndt_xform(R, t, xf, yf, zf, q);
-        int32_t c[3];
-        if (!ndt_source_cell(ep.kp, q, c)) {   // non-finite or out of the key range: the point is skipped
-            if (keys_out) { keys_out[i] = NDT_KEY_EMPTY; mask_out[i] = 0; }
-            continue;
-        }
-        double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-        unsigned hitmask = 0;
+    for (int pr = 0; pr < K; ++pr) {
+        const int dx = pr == 1 ? -1 : pr == 2 ? 1 : 0, dy = pr == 3 ? -1 : pr == 4 ? 1 : 0, dz = pr == 5 ? -1 : pr == 6 ? 1 : 0;
+        live[pr] = cell_ok(c[0] + dx) && cell_ok(c[1] + dy) && cell_ok(c[2] + dz);
+        want[pr] = ckey + ((int64_t)dx << 42) + ((int64_t)dy << 21) + (int64_t)dz;
+        const uint32_t h = ndt_hash_fin((hx + (uint32_t)dx * NDT_HP0) ^ (hy + (uint32_t)dy * NDT_HP1) ^ (hz + (uint32_t)dz * NDT_HP2));
+        s0[pr] = h & mask;
+        const Key2* kp = (const Key2*)(keys + s0[pr]);   // keys[cap .. cap+3] mirror keys[0 .. 3]: no wrap
+        ka[pr] = kp[0];
+        kb[pr] = kp[1];
+    }
+    // resolve, branch-free: fs = slot that holds the wanted key (SLOT_NONE if absent), pending = chain goes on
+    uint32_t fs[K];
+    uint32_t cur[K];
+    unsigned pending = 0;
+#pragma unroll
+    for (int pr = 0; pr < K; ++pr) {
+        const int64_t w = want[pr];
+        const bool m0 = ka[pr].x == w, m1 = ka[pr].y == w, m2 = kb[pr].x == w, m3 = kb[pr].y == w;
+        const bool e0 = ka[pr].x == NDT_KEY_EMPTY, e1 = ka[pr].y == NDT_KEY_EMPTY, e2 = kb[pr].x == NDT_KEY_EMPTY,
+                   e3 = kb[pr].y == NDT_KEY_EMPTY;
+        // first position that ends the chain (match or empty); the map never holds a key twice
+        const uint32_t off = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
+        const bool found = m0 || (!e0 && (m1 || (!e1 && (m2 || (!e2 && m3)))));
+        const bool more = !(m0 || e0 || m1 || e1 || m2 || e2 || m3 || e3);
+        fs[pr] = (live[pr] && found) ? (s0[pr] + off) & mask : SLOT_NONE;
+        pending |= (live[pr] && more) ? 1u << pr : 0u;
+        cur[pr] = (s0[pr] + 4) & mask;
+    }
+    // ---- probe chains longer than four slots (rare): all probes advance together, one round trip per level
+    while (__any(pending != 0)) {
+        int64_t kx[K];
+#pragma unroll
+        for (int pr = 0; pr < K; ++pr) kx[pr] = keys[cur[pr]];
 #pragma unroll
         for (int pr = 0; pr < K; ++pr) {
-            const int32_t n0 = c[0] + NB7[pr][0], n1 = c[1] + NB7[pr][1], n2 = c[2] + NB7[pr][2];
-            if (!ndt_in_range((double)n0) || !ndt_in_range((double)n1) || !ndt_in_range((double)n2)) continue;
-            const int64_t key = ndt_pack(n0, n1, n2);
-            uint64_t slot = ndt_mix64((uint64_t)key) & mask;
-            int4 head;
-            bool found = false;
-            for (;;) {
-                head = *(const int4*)&slots[slot];
-                const int64_t k = ((int64_t)(uint32_t)head.y << 32) | (uint32_t)head.x;
-                if (k == key) { found = true; break; }
-                if (k == NDT_KEY_EMPTY) break;
-                slot = (slot + 1) & mask;
-            }
-            if (!found || !head.z) continue;
-            const float4 p1 = *((const float4*)&slots[slot] + 1);   // off.xyz, i00
-            const float4 p2 = *((const float4*)&slots[slot] + 2);   // i01 i02 i11 i12
-            const double i00 = p1.w, i01 = p2.x, i02 = p2.y, i11 = p2.z, i12 = p2.w, i22 = __int_as_float(head.w);
-            acc[29] += 1.0;
-            const double e0 = (q[0] - (double)n0 * ep.kp.res_d) - (double)p1.x;
-            const double e1 = (q[1] - (double)n1 * ep.kp.res_d) - (double)p1.y;
-            const double e2 = (q[2] - (double)n2 * ep.kp.res_d) - (double)p1.z;
-            const double g0 = (i00 * e0 + i01 * e1) + i02 * e2;
-            const double g1 = (i01 * e0 + i11 * e1) + i12 * e2;
-            const double g2 = (i02 * e0 + i12 * e1) + i22 * e2;
-            const double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
-            if (isnan(chi2) || chi2 > ep.outlier_th) continue;
-            hitmask |= 1u << pr;
-            S[0] += i00; S[1] += i01; S[2] += i02; S[3] += i11; S[4] += i12; S[5] += i22;
-            g[0] += g0; g[1] += g1; g[2] += g2;
-            acc[27] += chi2;
-            acc[28] += 1.0;
+            const bool pend = (pending >> pr) & 1u;
+            const bool hit = pend && kx[pr] == want[pr], stop = pend && (hit || kx[pr] == NDT_KEY_EMPTY);
+            fs[pr] = hit ? cur[pr] : fs[pr];
+            pending &= stop ? ~(1u << pr) : ~0u;
+            cur[pr] = (pend && !stop) ? (cur[pr] + 1) & mask : cur[pr];
         }
-        if (keys_out) { keys_out[i] = ndt_pack(c[0], c[1], c[2]); mask_out[i] = (uint8_t)hitmask; }
-        if (!hitmask) continue;
-        // A = -R hat(q):  H = [A^T S A, A^T S; S A, S],  b = [-A^T g; -g]
-        const double x = xf, y = yf, z = zf;
-        double A[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            A[r][0] = -(R[3 * r + 1] * z - R[3 * r + 2] * y);
-            A[r][1] = -(R[3 * r + 2] * x - R[3 * r + 0] * z);
-            A[r][2] = -(R[3 * r + 0] * y - R[3 * r + 1] * x);
-        }
-        const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
-        double SA[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) SA[r][cc] = (Sm[r][0] * A[0][cc] + Sm[r][1] * A[1][cc]) + Sm[r][2] * A[2][cc];
-        // upper triangle of the 6x6, row-major: row r holds columns r..5
-        // rows 0..2 (rotation): [A^T S A](r, r..2), [A^T S](r, 0..2)
-        int tix = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int cc = r; cc < 3; ++cc) acc[tix++] += (A[0][r] * SA[0][cc] + A[1][r] * SA[1][cc]) + A[2][r] * SA[2][cc];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) acc[tix++] += SA[cc][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cc = r; cc < 3; ++cc) acc[tix++] += Sm[r][cc];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) acc[21 + r] += -((A[0][r] * g[0] + A[1][r] * g[1]) + A[2][r] * g[2]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) acc[24 + r] += -g[r];
     }
+    // ---- round 2: payload of every matched slot (slot 0 stands in for a miss), all in flight together
+    int4 hd[K];
+    float4 p1[K], p2[K];
+#pragma unroll
+    for (int pr = 0; pr < K; ++pr) {
+        const int4* sp = (const int4*)(slots + (fs[pr] != SLOT_NONE ? fs[pr] : 0u));
+        hd[pr] = sp[0];                        // key, valid, i22
+        p1[pr] = *(const float4*)(sp + 1);     // off.xyz, i00
+        p2[pr] = *(const float4*)(sp + 2);     // i01 i02 i11 i12
+    }
+    double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    unsigned hitmask = 0;
+#pragma unroll
+    for (int pr = 0; pr < K; ++pr) {
+        const int dx = pr == 1 ? -1 : pr == 2 ? 1 : 0, dy = pr == 3 ? -1 : pr == 4 ? 1 : 0, dz = pr == 5 ? -1 : pr == 6 ? 1 : 0;
+        const bool vox = fs[pr] != SLOT_NONE && hd[pr].z != 0;      // a valid voxel was found
+        const double i00 = p1[pr].w, i01 = p2[pr].x, i02 = p2[pr].y, i11 = p2[pr].z, i12 = p2[pr].w, i22 = __int_as_float(hd[pr].w);
+        const double e0 = (q[0] - (double)(c[0] + dx) * ep.kp.res_d) - (double)p1[pr].x;
+        const double e1 = (q[1] - (double)(c[1] + dy) * ep.kp.res_d) - (double)p1[pr].y;
+        const double e2 = (q[2] - (double)(c[2] + dz) * ep.kp.res_d) - (double)p1[pr].z;
+        const double g0 = (i00 * e0 + i01 * e1) + i02 * e2;
+        const double g1 = (i01 * e0 + i11 * e1) + i12 * e2;
+        const double g2 = (i02 * e0 + i12 * e1) + i22 * e2;
+        const double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
+        const bool ok = vox && chi2 <= ep.outlier_th;               // false for NaN
+        hitmask |= ok ? 1u << pr : 0u;
+        // w is exactly 0 or 1 and every operand is finite (payloads of valid voxels are finite, slot 0 stands in for
+        // misses), so fma(w, v, s) equals the plain s + v when the residual is accepted and s otherwise
+        const double w = ok ? 1.0 : 0.0;
+        acc[ACC_HITS] += vox ? 1.0 : 0.0;
+        S[0] = fma(w, i00, S[0]); S[1] = fma(w, i01, S[1]); S[2] = fma(w, i02, S[2]);
+        S[3] = fma(w, i11, S[3]); S[4] = fma(w, i12, S[4]); S[5] = fma(w, i22, S[5]);
+        g[0] = fma(w, g0, g[0]); g[1] = fma(w, g1, g[1]); g[2] = fma(w, g2, g[2]);
+        acc[ACC_CHI2] = fma(w, chi2, acc[ACC_CHI2]);
+        acc[ACC_NEFF] += w;
+    }
+    if (!__any(hitmask != 0)) return 0;
+    // A = -R hat(q):  H = [A^T S A, A^T S; S A, S],  b = [-A^T g; -g]
+    const double x = xf, y = yf, z = zf;
+    const double* R = P.R;
+    // (explicit fma from here on: this part is compared at the 1e-5 tolerance, not bit for bit)
+    double A[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        A[r][0] = fma(R[3 * r + 2], y, -(R[3 * r + 1] * z));
+        A[r][1] = fma(R[3 * r + 0], z, -(R[3 * r + 2] * x));
+        A[r][2] = fma(R[3 * r + 1], x, -(R[3 * r + 0] * y));
+    }
+    const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+    double SA[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) SA[r][cc] = fma(Sm[r][2], A[2][cc], fma(Sm[r][1], A[1][cc], Sm[r][0] * A[0][cc]));
+    // upper triangle of the 6x6, row-major: rows 0..2 = [A^T S A](r, r..2) then [A^T S](r, 0..2); rows 3..5 = S
+    int tix = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = r; cc < 3; ++cc) { acc[tix] = fma(A[0][r], SA[0][cc], fma(A[1][r], SA[1][cc], fma(A[2][r], SA[2][cc], acc[tix]))); ++tix; }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) acc[tix++] += SA[cc][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = r; cc < 3; ++cc) acc[tix++] += Sm[r][cc];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[21 + r] = fma(-A[0][r], g[0], fma(-A[1][r], g[1], fma(-A[2][r], g[2], acc[21 + r])));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[24 + r] -= g[r];
+    return hitmask;
+}
 
-    // lanes -> wave: fixed shuffle tree
+// Butterfly reduce-scatter of 32 per-lane doubles over the 64 lanes of a wave: after it, lanes 2i and 2i+1
+// both hold the wave total of acc[i].  32 exchanges; the summation tree is fixed.
+// Butterfly reduce-scatter of 32 per-lane doubles over the 64 lanes of a wave: after it, lanes 2i and 2i+1 both
+// hold the wave total of acc[i].  31 exchanges in a fixed tree.  The two widest levels use the gfx950 row-swap
+// instructions (v_permlane32_swap / v_permlane16_swap: no select, no LDS crossbar); the rest are lane shuffles.
+__device__ __forceinline__ double swap_add32(double a, double b) {   // lanes <32: a + a(lane+32); lanes >=32: b(lane-32) + b
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {   // even 16-lane rows keep a, odd rows keep b
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+template <int HALF, int BIT>
+__device__ __forceinline__ void rs_step(double* acc, int lane) {
+    const bool up = (lane & BIT) != 0;
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) {
-        double v = acc[j];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
-        acc[j] = v;
+    for (int j = 0; j < HALF; ++j) {
+        const double send = up ? acc[j] : acc[j + HALF];
+        const double keep = up ? acc[j + HALF] : acc[j];
+        acc[j] = keep + __shfl_xor(send, BIT);
     }
+}
+__device__ __forceinline__ double wave_reduce_scatter32(double* acc) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = swap_add32(acc[j], acc[j + 16]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = swap_add16(acc[j], acc[j + 8]);
+    rs_step<4, 8>(acc, lane);
+    rs_step<2, 4>(acc, lane);
+    rs_step<1, 2>(acc, lane);
+    return acc[0] + __shfl_xor(acc[0], 1);
+}
+
+// rows: partials[blockIdx.x][32]
+__device__ __forceinline__ void block_store_row(double* acc, double* __restrict__ row_out) {
     __shared__ double sm[RES_THREADS / 64][ACC_N];
+    const double v = wave_reduce_scatter32(acc);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) sm[w][j] = acc[j];
-        sm[w][30] = 0.0; sm[w][31] = 0.0;
-    }
+    if (!(lane & 1)) sm[w][lane >> 1] = v;
     __syncthreads();
-    if (threadIdx.x < ACC_N) {
-        double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-        partials[(size_t)blockIdx.x * ACC_N + threadIdx.x] = v;
+    if (threadIdx.x < ACC_N)
+        row_out[threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+
+template <int K, bool CELLS>
+__global__ __launch_bounds__(RES_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                          const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
+                                                          const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st,
+                                                          EvalParams ep, double* __restrict__ partials, int force, int64_t* keys_out,
+                                                          uint8_t* mask_out) {
+    // the first point's coordinates are requested before the state is read, so the two misses overlap
+    int i = blockIdx.x * RES_THREADS + threadIdx.x;
+    float xf = 0.f, yf = 0.f, zf = 0.f;
+    if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    if (!force && st->done) return;
+    Pose P;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) P.R[j] = st->R[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P.t[j] = st->t[j];
+    double acc[ACC_N];
+#pragma unroll
+    for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
+    while (i < n) {
+        int64_t ck;
+        const unsigned hm = point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        if (CELLS) { keys_out[i] = ck; mask_out[i] = (uint8_t)hm; }
+        i += gridDim.x * RES_THREADS;
+        if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     }
+    block_store_row(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
 int residual_grid(size_t n) {
@@ -143,126 +247,155 @@ int residual_grid(size_t n) {
     return (int)g;
 }
 
-void launch_residual(const float* x, const float* y, const float* z, int n, const VoxSlot* slots, uint64_t mask,
+void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, hipStream_t s) {
-    if (ep.nearby == 7)
-        k_residual<7><<<grid, RES_THREADS, 0, s>>>(x, y, z, n, slots, mask, st, ep, partials, force, keys_out, mask_out);
-    else
-        k_residual<1><<<grid, RES_THREADS, 0, s>>>(x, y, z, n, slots, mask, st, ep, partials, force, keys_out, mask_out);
+#define LAUNCH(KK, CC) k_residual<KK, CC><<<grid, RES_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st, ep, partials, force, keys_out, mask_out)
+    if (ep.nearby == 7) { if (keys_out) LAUNCH(7, true); else LAUNCH(7, false); }
+    else { if (keys_out) LAUNCH(1, true); else LAUNCH(1, false); }
+#undef LAUNCH
 }
 
 // ------------------------------------------------------------------ fixed-order final sum + Gauss-Newton step
 
-__device__ inline bool chol_solve6(const double* H, const double* b, double* x) {
-    double L[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = H[i * 6 + j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                L[i][i] = sqrt(s);
-            } else L[i][j] = s / L[j][j];
+// 6x6 SPD solve, LDL^T with reciprocal pivots (6 divisions, no square roots); false if a pivot is not positive
+__device__ inline bool ldlt_solve6(const double* H, const double* b, double* x) {
+    double L[6][6], d[6], id[6];
+    for (int j = 0; j < 6; ++j) {
+        double s = H[j * 6 + j];
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k] * d[k];
+        if (!(s > 0.0)) return false;
+        d[j] = s; id[j] = 1.0 / s;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = H[i * 6 + j];
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v * id[j];
         }
+    }
     double y[6];
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
         for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s / L[i][i];
+        y[i] = s;
     }
     for (int i = 5; i >= 0; --i) {
-        double s = y[i];
+        double s = y[i] * id[i];
         for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
-        x[i] = s / L[i][i];
+        x[i] = s;
     }
     return true;
 }
 
-// R <- R Exp(w), t <- t + v  (Exp: Rodrigues as src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad)
-__device__ void gn_step(GnState* st, const SolveParams& sp) {
-    const double* acc = st->acc;
+// One Gauss-Newton step from the reduced accumulators: dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6]
+// (Exp: Rodrigues as src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad).
+__device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp) {
     if ((long long)acc[ACC_NEFF] < (long long)sp.min_effective_pts) { st->status = NDT_ERR_TOO_FEW_POINTS; st->done = 1; return; }
     double H[36], b[6], dx[6];
     int t = 0;
+#pragma unroll
     for (int r = 0; r < 6; ++r)
+#pragma unroll
         for (int c = r; c < 6; ++c, ++t) { H[r * 6 + c] = acc[t]; H[c * 6 + r] = acc[t]; }
+#pragma unroll
     for (int r = 0; r < 6; ++r) b[r] = acc[21 + r];
-    if (!chol_solve6(H, b, dx)) { st->status = NDT_ERR_SINGULAR; st->done = 1; return; }
+    if (!ldlt_solve6(H, b, dx)) { st->status = NDT_ERR_SINGULAR; st->done = 1; return; }
     double nrm = 0.0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) { st->dx[j] = dx[j]; nrm += dx[j] * dx[j]; }
     nrm = sqrt(nrm);
     double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     const double th = sqrt((dx[0] * dx[0] + dx[1] * dx[1]) + dx[2] * dx[2]);
     if (th > 1e-7) {
-        const double a0 = dx[0] / th, a1 = dx[1] / th, a2 = dx[2] / th;
+        const double ith = 1.0 / th;
+        const double a0 = dx[0] * ith, a1 = dx[1] * ith, a2 = dx[2] * ith;
         const double Km[9] = {0, -a2, a1, a2, 0, -a0, -a1, a0, 0};
-        const double s = sin(th), c1 = 1.0 - cos(th);
+        double s, c;
+        sincos(th, &s, &c);
+        const double c1 = 1.0 - c;
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double kk = (Km[3 * i] * Km[j] + Km[3 * i + 1] * Km[3 + j]) + Km[3 * i + 2] * Km[6 + j];
                 E[3 * i + j] += s * Km[3 * i + j] + c1 * kk;
             }
     }
     double Rn[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) Rn[3 * i + j] = (st->R[3 * i] * E[j] + st->R[3 * i + 1] * E[3 + j]) + st->R[3 * i + 2] * E[6 + j];
+#pragma unroll
     for (int j = 0; j < 9; ++j) st->R[j] = Rn[j];
+#pragma unroll
     for (int j = 0; j < 3; ++j) st->t[j] += dx[3 + j];
     st->dx_norm = nrm;
-    st->iter += 1;
+    const int it = st->iter + 1;
+    st->iter = it;
     if (nrm < sp.eps) { st->converged = 1; st->done = 1; }
-    if (st->iter >= sp.max_iterations) st->done = 1;
+    if (it >= sp.max_iterations) st->done = 1;
 }
 
 #define RED_THREADS 1024
-// thread (row r = tid / 32, column c = tid % 32) adds partial rows r, r+32, ... in order; rows are then
-// combined by a fixed binary tree in LDS.
-__global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
-                                                              SolveParams sp, int do_solve, int force) {
-    if (!force && st->done) return;
-    __shared__ double sm[32][ACC_N + 1];
+// thread (row r = tid / 32, column c = tid % 32) adds partial rows r, r+32, ... in order; the 32 row sums are then
+// combined by a fixed binary tree in LDS.  Result in sm[0][*].
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], bool live) {
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     double v = 0.0;
-    for (int i = r; i < n_partials; i += 32) v += partials[(size_t)i * ACC_N + c];
+    if (live) {
+        // rows r, r+32, ... : eight loads in flight at a time (they are L2 misses: other CUs just wrote them),
+        // added strictly in row order
+        for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 32 * u;
+                x[u] = i < n_partials ? partials[(size_t)i * ACC_N + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += x[u];
+        }
+    }
     sm[r][c] = v;
     __syncthreads();
+#pragma unroll
     for (int o = 16; o >= 1; o >>= 1) {
         if (r < o) sm[r][c] += sm[r + o][c];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
+                                                              SolveParams sp, int do_solve, int force) {
+    __shared__ double sm[32][ACC_N + 1];
+    // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
+    // discards the result
+    reduce_rows(partials, n_partials, sm, true);
+    if (!force && st->done) return;
     if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
-    __syncthreads();
     if (do_solve && threadIdx.x == 0) {
-        __threadfence_block();
-        gn_step(st, sp);
+        double acc[ACC_N];
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[0][j];
+        gn_step(st, acc, sp);
     }
 }
 // multi-GPU form: the local sum goes to a row that RCCL all-reduces, and the step reads the reduced row
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __restrict__ partials, int n_partials, const GnState* st,
                                                              double* row_out, int force) {
     __shared__ double sm[32][ACC_N + 1];
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-    const bool live = force || !st->done;     // a finished state contributes zeros (its partials are stale)
-    double v = 0.0;
-    if (live) for (int i = r; i < n_partials; i += 32) v += partials[(size_t)i * ACC_N + c];
-    sm[r][c] = v;
-    __syncthreads();
-    for (int o = 16; o >= 1; o >>= 1) {
-        if (r < o) sm[r][c] += sm[r + o][c];
-        __syncthreads();
-    }
+    reduce_rows(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
     if (threadIdx.x < ACC_N) row_out[threadIdx.x] = sm[0][threadIdx.x];
 }
 __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp, int do_solve, int force) {
     if (!force && st->done) return;
     if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = reduced[threadIdx.x];
-    __syncthreads();
-    if (do_solve && threadIdx.x == 0) gn_step(st, sp);
+    if (do_solve && threadIdx.x == 0) {
+        double acc[ACC_N];
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) acc[j] = reduced[j];
+        gn_step(st, acc, sp);
+    }
 }
 
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, hipStream_t s) {

@@ -1,0 +1,11 @@
+"""Short profiling driver: configs[2] workload (cached by bench.py under /tmp), N aligns.  Used under rocprofv3."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, lio_slam_amd as la
+n_align = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+w = bench.load_workload(2, 0, 1, None, False)
+ndt = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
+ndt.set_target(w["map"]); ndt.set_source(w["scan"])
+for _ in range(n_align):
+    r = ndt.align(w["guess"])
+print("done", r["iterations"], ndt.num_voxels())
