@@ -85,6 +85,8 @@ typedef struct ndt_result {
     int64_t n_effective; /* accepted residuals in the reported evaluation                   */
     int32_t iterations;  /* Gauss-Newton steps taken                                        */
     int32_t converged;   /* 1 if |dx| < eps was reached                                     */
+    int32_t status;      /* NDT_OK or the error of this alignment (what ndt_align returns)  */
+    int32_t reserved;
 } ndt_result;
 
 /* Fills *cfg with the defaults chosen in SURVEY.md Appendix B. */
@@ -151,7 +153,8 @@ void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz);
 /* Offline replay (BASELINE.json configs[4]): align `n_pairs` hypotheses against
  * the resident map in one batched Gauss-Newton loop.  `pts` holds all scans
  * back to back; scan s is points [scan_offsets[s], scan_offsets[s+1]);
- * pair p uses scan pair_scan[p] (NULL: pair p uses scan p) from guesses[16*p]. */
+ * pair p uses scan pair_scan[p] (NULL: pair p uses scan p) from guesses[16*p].
+ * Returns NDT_OK when the batch ran; results[p].status tells how pair p ended. */
 int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride_bytes,
                     const int64_t* scan_offsets, size_t n_scans, const int32_t* pair_scan,
                     size_t n_pairs, const double* guesses, ndt_result* results);

@@ -48,7 +48,7 @@ class Result(C.Structure):
     _fields_ = [
         ("T", C.c_double * 16), ("H", C.c_double * 36), ("b", C.c_double * 6), ("chi2", C.c_double),
         ("last_dx_norm", C.c_double), ("n_effective", C.c_int64), ("iterations", C.c_int32),
-        ("converged", C.c_int32),
+        ("converged", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -210,6 +210,24 @@ class NDT:
                           chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations, converged=bool(r.converged),
                           last_dx_norm=r.last_dx_norm)
         return self.final
+
+    def align_batch(self, scans, guesses, pair_scan=None):
+        """Offline replay: align many (scan, guess) pairs against the resident map in one batched Gauss-Newton loop.
+
+        scans: list of float32 (n_i, 3) arrays; guesses: (n_pairs, 4, 4); pair_scan: scan index per pair (None: pair p
+        uses scan p).  Returns a list of result dicts (same keys as align(), plus 'status')."""
+        scans = [np.ascontiguousarray(a, dtype=np.float32)[:, :3] for a in scans]
+        pts = np.ascontiguousarray(np.concatenate(scans)) if scans else np.zeros((0, 3), np.float32)
+        off = np.zeros(len(scans) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in scans])
+        g = np.ascontiguousarray(np.stack([_T(T) for T in guesses]))
+        n_pairs = len(g)
+        ps = None if pair_scan is None else np.ascontiguousarray(pair_scan, dtype=np.int32)
+        res = (Result * n_pairs)()
+        self._chk(lib().ndt_align_batch(self._h, pts.ctypes.data, 12, off.ctypes.data, len(scans),
+                                        None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data, res))
+        return [dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6),
+                     b=np.array(r.b), chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations,
+                     converged=bool(r.converged), last_dx_norm=r.last_dx_norm) for r in res]
 
     def getFinalTransformation(self): return self.final["T"]
     def hasConverged(self): return self.final["converged"]

@@ -68,6 +68,8 @@ struct ndt_handle {
     void* comm = nullptr;
     int n_ranks = 1;
     DevBuf comm_rows;            // [2][ACC_N] doubles: all-reduce send / receive rows
+    // offline replay batch
+    DevBuf braw, bx, by, bz, boff, bpair, bstates, bpartials, bdone;
 };
 
 #define H_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
@@ -127,7 +129,8 @@ void ndt_destroy(ndt_handle* h) {
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     map_free(h->map);
     h->work.release();
-    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->cell_keys, &h->cell_mask, &h->comm_rows};
+    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->cell_keys, &h->cell_mask, &h->comm_rows, &h->braw, &h->bx, &h->by, &h->bz,
+                      &h->boff, &h->bpair, &h->bstates, &h->bpartials, &h->bdone};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->d_state) (void)hipFree(h->d_state);
@@ -342,6 +345,7 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     out->last_dx_norm = loop.dx_norm;
     out->iterations = loop.iter;
     out->converged = loop.converged;
+    out->status = loop.status;
     if (h->prof) { h->prof_hits += st->acc[ACC_HITS]; h->prof_pts += (double)h->n_src; }
     if (loop.status != NDT_OK) {
         h->err = loop.status == NDT_ERR_TOO_FEW_POINTS ? "fewer accepted residuals than min_effective_pts" : "Hessian not positive definite";
@@ -379,10 +383,98 @@ void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz) {
     if (iz) *iz = c;
 }
 
-int ndt_align_batch(ndt_handle* h, const void*, size_t, const int64_t*, size_t, const int32_t*, size_t, const double*, ndt_result*) {
+int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t* scan_offsets, size_t n_scans,
+                    const int32_t* pair_scan, size_t n_pairs, const double* guesses, ndt_result* results) {
     if (!h) return NDT_ERR_INVALID_ARG;
-    h->err = "ndt_align_batch: not built yet";
-    return NDT_ERR_INVALID_ARG;
+    if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
+    if (!scan_offsets || !n_scans || !n_pairs || !guesses || !results || stride < 12 || (stride & 3)) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
+    if (!pair_scan && n_pairs != n_scans) { h->err = "without pair_scan there must be one scan per pair"; return NDT_ERR_INVALID_ARG; }
+    if (h->comm) { h->err = "batched replay has no collective: destroy the communicator first"; return NDT_ERR_INVALID_ARG; }
+    int64_t max_pts = 0;
+    for (size_t i = 0; i < n_scans; ++i) {
+        const int64_t m = scan_offsets[i + 1] - scan_offsets[i];
+        if (m < 0 || scan_offsets[0] != 0) { h->err = "scan_offsets must start at 0 and not decrease"; return NDT_ERR_INVALID_ARG; }
+        max_pts = std::max(max_pts, m);
+    }
+    const size_t total = (size_t)scan_offsets[n_scans];
+    if ((total && !pts) || max_pts >= (1ll << 31)) { h->err = "bad point buffer"; return NDT_ERR_INVALID_ARG; }
+    if (pair_scan)
+        for (size_t p = 0; p < n_pairs; ++p)
+            if (pair_scan[p] < 0 || (size_t)pair_scan[p] >= n_scans) { h->err = "pair_scan out of range"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = h->stream;
+    // upload: scans (AoS -> SoA), offsets, pair table, initial states
+    H_TRY(h->braw.ensure(total * stride + 16));
+    H_TRY(h->bx.ensure(total * 4 + 16)); H_TRY(h->by.ensure(total * 4 + 16)); H_TRY(h->bz.ensure(total * 4 + 16));
+    if (total) {
+        H_TRY(hipMemcpyAsync(h->braw.p, pts, total * stride, hipMemcpyDefault, s));
+        H_TRY(unpack_points_soa(h->braw.p, total, stride, h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), s));
+    }
+    H_TRY(h->boff.ensure((n_scans + 1) * 8));
+    H_TRY(hipMemcpyAsync(h->boff.p, scan_offsets, (n_scans + 1) * 8, hipMemcpyHostToDevice, s));
+    if (pair_scan) {
+        H_TRY(h->bpair.ensure(n_pairs * 4));
+        H_TRY(hipMemcpyAsync(h->bpair.p, pair_scan, n_pairs * 4, hipMemcpyHostToDevice, s));
+    }
+    std::vector<GnState> st(n_pairs);
+    for (size_t p = 0; p < n_pairs; ++p) state_from_T(&st[p], guesses + 16 * p);
+    H_TRY(h->bstates.ensure(n_pairs * sizeof(GnState)));
+    H_TRY(hipMemcpyAsync(h->bstates.p, st.data(), n_pairs * sizeof(GnState), hipMemcpyHostToDevice, s));
+    const int rows = residual_grid((size_t)max_pts);
+    H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
+    H_TRY(h->bdone.ensure(256));
+    H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
+    H_TRY(hipStreamSynchronize(s));           // the caller's buffers (and st) are free again
+
+    const EvalParams ep = eval_params(h);
+    const SolveParams sp = solve_params(h);
+    GnState* dst = h->bstates.as<GnState>();
+    const int32_t* dps = pair_scan ? h->bpair.as<int32_t>() : nullptr;
+    const size_t CH = 32768;                  // gridDim.y limit is 65535
+    auto pass = [&](int do_solve, int force) {
+        for (size_t p0 = 0; p0 < n_pairs; p0 += CH) {
+            const int np = (int)std::min(CH, n_pairs - p0);
+            launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(), dps, h->map.keys,
+                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, s);
+            launch_reduce_solve_batch(h->bpartials.as<double>() + p0 * (size_t)rows * ACC_N, rows, dst + p0, np, sp, do_solve, force,
+                                      h->bdone.as<int32_t>(), s);
+        }
+    };
+    const int max_it = h->cfg.max_iterations;
+    const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
+    for (int queued = 0; queued < max_it;) {
+        const int m = std::min(chunk, max_it - queued);
+        for (int i = 0; i < m; ++i) pass(1, 0);
+        queued += m;
+        H_TRY(hipGetLastError());
+        int32_t n_done = 0;
+        H_TRY(hipMemcpyAsync(&n_done, h->bdone.p, 4, hipMemcpyDeviceToHost, s));
+        H_TRY(hipStreamSynchronize(s));
+        if ((size_t)n_done >= n_pairs) break;
+    }
+    std::vector<GnState> loop(n_pairs);
+    H_TRY(hipMemcpyAsync(loop.data(), dst, n_pairs * sizeof(GnState), hipMemcpyDeviceToHost, s));
+    H_TRY(hipStreamSynchronize(s));
+    if (h->cfg.final_eval) {
+        pass(0, 1);
+        H_TRY(hipGetLastError());
+        H_TRY(hipMemcpyAsync(st.data(), dst, n_pairs * sizeof(GnState), hipMemcpyDeviceToHost, s));
+        H_TRY(hipStreamSynchronize(s));
+    } else st = loop;
+    for (size_t p = 0; p < n_pairs; ++p) {
+        ndt_result* out = results + p;
+        memset(out, 0, sizeof *out);
+        const GnState* fin = (loop[p].status == NDT_OK) ? &st[p] : &loop[p];
+        T_from_state(&loop[p], out->T);
+        unpack_acc(fin->acc, out->H, out->b);
+        out->chi2 = fin->acc[ACC_CHI2];
+        out->n_effective = (int64_t)fin->acc[ACC_NEFF];
+        out->last_dx_norm = loop[p].dx_norm;
+        out->iterations = loop[p].iter;
+        out->converged = loop[p].converged;
+        out->status = loop[p].status;
+    }
+    return NDT_OK;
 }
 
 int ndt_comm_unique_id(char id_out[128]) {

@@ -240,6 +240,40 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(const float* __restric
     block_store_row(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
+// Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
+// pair's scan.  Scans are stored back to back in xs/ys/zs; pair p reads scan pair_scan[p] (or p) and its own GnState.
+template <int K>
+__global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                                const float* __restrict__ zs, const int64_t* __restrict__ scan_off,
+                                                                const int32_t* __restrict__ pair_scan, const int64_t* __restrict__ keys,
+                                                                const VoxSlot* __restrict__ slots, uint32_t mask,
+                                                                const GnState* __restrict__ states, EvalParams ep,
+                                                                double* __restrict__ partials, int rows_per_pair, int force) {
+    const int pair = blockIdx.y;
+    const int scan = pair_scan ? pair_scan[pair] : pair;
+    const int64_t lo = scan_off[scan], hi = scan_off[scan + 1];
+    const GnState* st = states + pair;
+    int64_t i = lo + (int64_t)blockIdx.x * RES_THREADS + threadIdx.x;
+    float xf = 0.f, yf = 0.f, zf = 0.f;
+    if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    if (!force && st->done) return;
+    Pose P;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) P.R[j] = st->R[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P.t[j] = st->t[j];
+    double acc[ACC_N];
+#pragma unroll
+    for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
+    while (i < hi) {
+        int64_t ck;
+        point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        i += (int64_t)gridDim.x * RES_THREADS;
+        if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    }
+    block_store_row(acc, partials + ((size_t)pair * rows_per_pair + blockIdx.x) * ACC_N);
+}
+
 int residual_grid(size_t n) {
     size_t g = (n + RES_THREADS - 1) / RES_THREADS;
     if (g < 1) g = 1;
@@ -337,19 +371,20 @@ __device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp) {
 }
 
 #define RED_THREADS 1024
-// thread (row r = tid / 32, column c = tid % 32) adds partial rows r, r+32, ... in order; the 32 row sums are then
+// thread (row group r = tid / 32, column c = tid % 32) adds partial rows r, r+RG, ... in order; the RG sums are then
 // combined by a fixed binary tree in LDS.  Result in sm[0][*].
+template <int RG>
 __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], bool live) {
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     double v = 0.0;
     if (live) {
         // rows r, r+32, ... : eight loads in flight at a time (they are L2 misses: other CUs just wrote them),
         // added strictly in row order
-        for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
+        for (int i0 = r; i0 < n_partials; i0 += RG * 8) {
             double x[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 32 * u;
+                const int i = i0 + RG * u;
                 x[u] = i < n_partials ? partials[(size_t)i * ACC_N + c] : 0.0;
             }
 #pragma unroll
@@ -359,7 +394,7 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
     sm[r][c] = v;
     __syncthreads();
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) {
+    for (int o = RG / 2; o >= 1; o >>= 1) {
         if (r < o) sm[r][c] += sm[r + o][c];
         __syncthreads();
     }
@@ -370,7 +405,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
     __shared__ double sm[32][ACC_N + 1];
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
-    reduce_rows(partials, n_partials, sm, true);
+    reduce_rows<32>(partials, n_partials, sm, true);
     if (!force && st->done) return;
     if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
     if (do_solve && threadIdx.x == 0) {
@@ -384,7 +419,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __restrict__ partials, int n_partials, const GnState* st,
                                                              double* row_out, int force) {
     __shared__ double sm[32][ACC_N + 1];
-    reduce_rows(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
+    reduce_rows<32>(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
     if (threadIdx.x < ACC_N) row_out[threadIdx.x] = sm[0][threadIdx.x];
 }
 __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp, int do_solve, int force) {
@@ -398,6 +433,39 @@ __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp,
     }
 }
 
+#define BRED_THREADS 256
+// batched form: one block per pair; counts the pairs that finish in *n_done
+__global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
+                                                                     SolveParams sp, int do_solve, int force, int32_t* n_done) {
+    __shared__ double sm[BRED_THREADS / 32][ACC_N + 1];
+    GnState* st = states + blockIdx.x;
+    reduce_rows<BRED_THREADS / 32>(partials + (size_t)blockIdx.x * rows_per_pair * ACC_N, rows_per_pair, sm, true);
+    if (!force && st->done) return;
+    if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
+    if (do_solve && threadIdx.x == 0) {
+        double acc[ACC_N];
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[0][j];
+        gn_step(st, acc, sp);
+        if (st->done) atomicAdd(n_done, 1);
+    }
+}
+
+void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
+                           const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, hipStream_t s) {
+    dim3 grid((unsigned)rows_per_pair, (unsigned)n_pairs);
+    const int32_t* ps = pair_scan ? pair_scan + pair0 : nullptr;
+    // without pair_scan pair p reads scan p, so the offsets are shifted together with the states
+    const int64_t* so = pair_scan ? scan_off : scan_off + pair0;
+    double* pp = partials + (size_t)pair0 * rows_per_pair * ACC_N;
+    if (ep.nearby == 7) k_residual_batch<7><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    else k_residual_batch<1><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+}
+void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
+                               int do_solve, int force, int32_t* n_done, hipStream_t s) {
+    k_reduce_solve_batch<<<n_pairs, BRED_THREADS, 0, s>>>(partials, rows_per_pair, states, sp, do_solve, force, n_done);
+}
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, hipStream_t s) {
     k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force);
 }

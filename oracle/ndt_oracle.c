@@ -612,6 +612,7 @@ int ora_align(ora_handle* h, const double guess[16], ndt_result* out) {
     out->chi2 = acc[27];
     out->n_effective = (int64_t)acc[28];
     T_from_mat(R, t, out->T);
+    out->status = rc;
     return rc;
 }
 

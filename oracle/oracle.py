@@ -27,7 +27,7 @@ class Result(C.Structure):
     _fields_ = [
         ("T", C.c_double * 16), ("H", C.c_double * 36), ("b", C.c_double * 6), ("chi2", C.c_double),
         ("last_dx_norm", C.c_double), ("n_effective", C.c_int64), ("iterations", C.c_int32),
-        ("converged", C.c_int32),
+        ("converged", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
