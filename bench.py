@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — NDT scan-matching throughput on MI355X (BASELINE.json metric).
 
-Workload at N=1 (configs[2], the configuration the metric is quoted on): one HDL-64-shaped scan
-(~120k points) aligned against a GPU-resident voxel map built from a 2M-point keyframe map, NEARBY7,
-1.0 m voxels.  One step = one full `ndt_align` of the resident scan from the perturbed ("IMU-predicted")
-pose, with a fixed number of Gauss-Newton iterations (eps = 0, so no work can be skipped).
-value = source points x Gauss-Newton iterations per second, whole job.
+Workload (configs[2], the configuration the metric is quoted on): HDL-64-shaped scans (~118k points each)
+aligned against a GPU-resident voxel map built from a 2M-point keyframe map, NEARBY7, 1.0 m voxels, each
+from a perturbed ("IMU-predicted") pose with a fixed number of Gauss-Newton iterations (eps = 0, so no
+work can be skipped).  One step = one batched align of `--batch` independent scan-to-map pairs (offline
+replay; all scans resident in HBM).  value = source points x Gauss-Newton iterations per second, whole job.
+The online case (one scan at a time, what the SLAM pipeline does per frame) is timed too and reported in
+"single_scan" with its own roofline.
 
-N>1 (`torch.distributed.run`, one process per GPU): offline replay — every rank holds a replica of the
-map and aligns its own scans; no data-path collective; weak scaling.  `--mode sharded` instead shards one
-dense source cloud over the ranks with an RCCL all-reduce of the 29 H/b/chi2/n terms per iteration
-(configs[3]); it is also run as a secondary measurement after the main one when N>1.
+N>1 (`torch.distributed.run`, one process per GPU): every rank holds a replica of the map and replays its
+own batch; no data-path collective; weak scaling.  `--mode sharded` instead shards one source cloud over
+the ranks with an RCCL all-reduce of the 29 H/b/chi2/n terms per iteration (configs[3]).
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +32,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def algorithmic_bytes_per_point(k, h):
     """B_res = 12 (xyz) + 8 k (key slot per probe) + 40 h (payload per valid hit)."""
     return 12.0 + 8.0 * k + 40.0 * h
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic_r01.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        return d[kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def load_workload(index, rank, world, dist, small):
@@ -84,10 +94,11 @@ def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10, help="Gauss-Newton iterations per align (fixed)")
     ap.add_argument("--nearby", type=int, default=7)
+    ap.add_argument("--batch", type=int, default=16, help="scan-to-map pairs aligned together per step (replay mode)")
     ap.add_argument("--mode", choices=["replay", "sharded"], default="replay")
     ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -103,9 +114,27 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
     import lio_slam_amd as la
+    from lio_slam_amd import synth
 
     w = load_workload(2, rank, world, dist, a.small)
     ndt = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+
+    def barrier():
+        ndt.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def allmax(x):
+        if world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); return float(t[0])
+
+    def allsum(x):
+        if world == 1:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t); return float(t[0])
 
     t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
     t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = min(build_ms, 1e3 * (time.perf_counter() - t0))
@@ -115,74 +144,105 @@ def main():
         t0 = time.perf_counter(); ndt.add_target(w[f"scan{j}"], w[f"T{j}"]); ndt.synchronize()
         merge_ms.append(1e3 * (time.perf_counter() - t0))
 
+    # ---- the online case: ONE scan aligned at a time (what lio-slam's pipeline does per LiDAR frame)
+    single = None
+    if a.mode == "replay":
+        ndt.set_source(w["scan"])
+        n1 = ndt.source_size()
+        for _ in range(a.warmup):
+            r1 = ndt.align(w["guess"])
+        ndt.synchronize()
+        reps1 = max(20, a.steps)
+        t0 = time.perf_counter()
+        for _ in range(reps1):
+            r1 = ndt.align(w["guess"])
+        ndt.synchronize()
+        el1 = time.perf_counter() - t0
+        k1 = 0.5 * (ndt.time_residual(w["guess"], 300) + ndt.time_residual(r1["T"], 300))
+        ndt.profile(True); ndt.eval(w["guess"]); ndt.eval(r1["T"]); h1 = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
+        ach1 = n1 * algorithmic_bytes_per_point(a.nearby, h1) / (k1 * 1e-6) / 1e9
+        single = {"value": n1 * a.iters * reps1 / el1, "unit": "source-points*iters/s", "ms_per_align": 1e3 * el1 / reps1,
+                  "scans_per_s": reps1 / el1, "source_points": int(n1),
+                  "final_pose_error_m": float(np.linalg.norm((np.linalg.inv(w["T_true"]) @ r1["T"])[:3, 3])),
+                  "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
+                               "kernel": f"k_residual<{a.nearby}>", "kernel_avg_us": k1, "points_per_launch": int(n1),
+                               "hits_per_point": h1, "bytes_per_point": algorithmic_bytes_per_point(a.nearby, h1)}}
+
+    # ---- the timed workload
     if a.mode == "sharded":
-        scan_all, guess = w["scan"], w["guess"]
         from lio_slam_amd.shard import shard_range
+        scan_all, guess = w["scan"], w["guess"]
         lo, hi = shard_range(len(scan_all), rank, world)
-        scan = scan_all[lo:hi]
         if world > 1:
             ids = [la.NDT.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             ndt.comm_init(rank, world, ids[0])
-        total_pts = len(scan_all)
+        ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
+        pts_rank = float(ndt.source_size())
+        step = lambda: ndt.align(guess)
+        check = lambda r: r["iterations"] == a.iters
     else:
-        j = rank % 8
-        scan, guess = (w["scan"], w["guess"]) if rank == 0 else (w[f"scan{j}"], w[f"guess{j}"])
-        total_pts = None
-    ndt.set_source(scan)                      # resident in HBM before the timed region
-    n_src = ndt.source_size()
-
-    def barrier():
-        ndt.synchronize()
-        if world > 1:
-            dist.barrier()
+        # offline replay of configs[2]-sized pairs: `batch` independent (scan, initial pose) pairs per step, each rank
+        # its own scans (8 distinct scans along the trajectory x hypotheses), all resident in HBM
+        rng = np.random.Generator(np.random.PCG64(synth.seed_for(2) + 77 + rank))
+        scans = [w[f"scan{(j + rank) % 8}"] for j in range(min(8, a.batch))]
+        pair_scan = [p % len(scans) for p in range(a.batch)]
+        guesses = [w[f"guess{(p % len(scans) + rank) % 8}"] if p < len(scans) else
+                   w[f"T{(p % len(scans) + rank) % 8}"] @ synth.perturbation(rng) for p in range(a.batch)]
+        ndt.set_batch_sources(scans)                          # resident in HBM before the timed region
+        pts_rank = float(sum(len(scans[s]) for s in pair_scan))
+        step = lambda: ndt.align_batch_resident(guesses, pair_scan)
+        check = lambda r: all(x["iterations"] == a.iters and x["status"] == 0 for x in r)
 
     for _ in range(a.warmup):
-        r = ndt.align(guess)
+        r = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = ndt.align(guess)
+        r = step()
     ndt.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t[0])
-        cnt = torch.tensor([float(n_src)], dtype=torch.float64); dist.all_reduce(cnt); pts_all = float(cnt[0])
-    else:
-        pts_all = float(n_src)
-    assert r["iterations"] == a.iters, r
-    units = (float(total_pts) if a.mode == "sharded" else pts_all) * a.iters * a.steps
-    value = units / el
+    el = allmax(time.perf_counter() - t0)
+    assert check(r), "an align did not run its fixed iterations"
+    pts_all = allsum(pts_rank)
+    value = pts_all * a.iters * a.steps / el
 
-    # roofline of the dominant kernel (k_residual): HIP events on the engine's stream around back-to-back launches
-    # of that kernel alone, at the guess and at the converged pose (the two ends of the timed loop)
-    k_us = 0.5 * (ndt.time_residual(guess, 300) + ndt.time_residual(r["T"], 300))
-    ndt.profile(True)
-    ndt.eval(guess); ndt.eval(r["T"])
-    pr = ndt.profile_read()
-    ndt.profile(False)
-    h = pr["hits_per_point"]
+    # roofline of the dominant kernel: HIP events on the engine's stream around back-to-back launches of that
+    # kernel alone, right after the timed region (kept outside it so that `value` is undisturbed)
+    if a.mode == "sharded":
+        k_us = 0.5 * (ndt.time_residual(guess, 300) + ndt.time_residual(r["T"], 300))
+        ndt.profile(True); ndt.eval(guess); ndt.eval(r["T"]); h = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
+        ppl, kname = pts_rank, f"k_residual<{a.nearby}>"
+        err = None
+    else:
+        k_us, ppl, h = ndt.time_residual_batch(100)
+        kname = f"k_residual_batch<{a.nearby}>"
+        err = [float(np.linalg.norm((np.linalg.inv(w[f"T{(pair_scan[p] + rank) % 8}"]) @ r[p]["T"])[:3, 3])) for p in range(a.batch)]
     bpp = algorithmic_bytes_per_point(a.nearby, h)
-    achieved = n_src * bpp / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
+    achieved = ppl * bpp / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
 
     out = {
-        "metric": "NDT source-points*iters/sec (120k-pt scan vs 2M-pt map)", "value": value, "unit": "source-points*iters/s",
+        "metric": "NDT source-points*iters/sec (120k-pt scans vs 2M-pt map)", "value": value, "unit": "source-points*iters/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
         "higher_is_better": True, "scaling": "weak" if a.mode == "replay" else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("configs[2]: HDL-64-shaped scan vs GPU-resident voxel map of a 2M-pt keyframe map"
+        "config": {"workload": ("configs[2]: HDL-64-shaped scans (~118k pts) vs the GPU-resident voxel map of a 2M-pt keyframe map"
+                                + (f"; offline replay, {a.batch} independent scan-to-map pairs per step per GPU" if a.mode == "replay"
+                                   else "; one source cloud sharded over the ranks, RCCL all-reduce of H,b per iteration")
                                 + (" (SMALL 200k-pt map: not a valid number)" if a.small else "")),
-                   "mode": a.mode, "source_points_per_rank": int(n_src), "map_points": int(len(w["map"])),
+                   "mode": a.mode, "pairs_per_step_per_gpu": a.batch if a.mode == "replay" else 1,
+                   "source_points_per_step_per_gpu": int(pts_rank), "map_points": int(len(w["map"])),
                    "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0, "gn_iterations_per_align": a.iters,
                    "parallelism": f"{a.mode}{world}"},
-        "scans_per_s": a.steps * (world if a.mode == "replay" else 1) / el,
+        "scans_per_s": a.steps * (a.batch * world if a.mode == "replay" else 1) / el,
         "map_build_ms": build_ms, "keyframe_merge_ms": merge_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_residual<7>" if a.nearby == 7 else "k_residual<1>",
-                     "kernel_avg_us": k_us, "launches": 600, "bytes_per_point": bpp, "hits_per_point": h,
-                     "points_per_launch": int(n_src), "timing": "hipEvents on the engine stream around 300 back-to-back launches, at the guess and at the final pose"},
-        "final_pose_error_m": float(np.linalg.norm((np.linalg.inv(w["T_true"]) @ r["T"])[:3, 3])) if rank == 0 and a.mode == "replay" else None,
+                     "traffic": measured_traffic(kname.replace("k_residual_batch", "k_residual_batch") if a.batch == 16 or a.mode != "replay" else ""),
+                     "traffic_source": "profiles/traffic_r01.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, same workload)",
+                     "kernel": kname, "kernel_avg_us": k_us, "bytes_per_point": bpp, "hits_per_point": h,
+                     "points_per_launch": int(ppl),
+                     "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"},
+        "final_pose_error_m_max": max(err) if err else None,
+        "single_scan": single,
     }
     if rank == 0 and world == 1 and not a.no_cpu:
         out.update(time_cpu_baseline(w, a.iters, a.nearby))

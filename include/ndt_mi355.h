@@ -159,6 +159,12 @@ int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride_bytes,
                     const int64_t* scan_offsets, size_t n_scans, const int32_t* pair_scan,
                     size_t n_pairs, const double* guesses, ndt_result* results);
 
+/* The same in two steps, so that the scans stay resident in HBM across many batched aligns. */
+int ndt_set_batch_sources(ndt_handle* h, const void* pts, size_t stride_bytes, const int64_t* scan_offsets,
+                          size_t n_scans);
+int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_pairs, const double* guesses,
+                             ndt_result* results);
+
 /* Large clouds (BASELINE.json configs[3]): each rank holds a shard of the source
  * and a replica of the map; ndt_align/ndt_eval then all-reduce the 29 H/b/chi2/n
  * terms over RCCL on every Gauss-Newton iteration.  Rank 0 calls
@@ -178,6 +184,11 @@ int ndt_profile_read(ndt_handle* h, double* residual_kernel_us, int64_t* residua
 /* Mean duration of the residual kernel alone: `reps` back-to-back launches at pose T between two HIP events on
  * the handle's stream (what bench.py's roofline uses; agrees with rocprofv3 --kernel-trace). */
 int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_per_launch);
+
+/* The same for the batched residual kernel, on the batch left resident by the last ndt_align_batch (poses as
+ * that call left them).  points_per_launch / hits_per_point may be NULL. */
+int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, double* points_per_launch,
+                            double* hits_per_point);
 
 /* Blocks until all work queued on the handle's stream has finished. */
 int ndt_synchronize(ndt_handle* h);

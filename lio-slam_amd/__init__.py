@@ -23,8 +23,8 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
-    "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_comm_unique_id",
-    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_synchronize",
+    "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
 
@@ -92,12 +92,15 @@ def lib():
     L.ndt_pack_key.argtypes = [C.c_int32] * 3
     L.ndt_unpack_key.argtypes = [C.c_int64, vp, vp, vp]
     L.ndt_align_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.ndt_set_batch_sources.argtypes = [vp, vp, sz, vp, sz]
+    L.ndt_align_batch_resident.argtypes = [vp, vp, sz, vp, vp]
     L.ndt_comm_unique_id.argtypes = [vp]
     L.ndt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ndt_comm_destroy.argtypes = [vp]
     L.ndt_profile.argtypes = [vp, C.c_int]
     L.ndt_profile_read.argtypes = [vp, vp, vp, vp]
     L.ndt_time_residual.argtypes = [vp, vp, C.c_int, vp]
+    L.ndt_time_residual_batch.argtypes = [vp, C.c_int, vp, vp, vp]
     L.ndt_synchronize.argtypes = [vp]
     L.ndt_last_error.restype = C.c_char_p
     L.ndt_last_error.argtypes = [vp]
@@ -216,15 +219,22 @@ class NDT:
 
         scans: list of float32 (n_i, 3) arrays; guesses: (n_pairs, 4, 4); pair_scan: scan index per pair (None: pair p
         uses scan p).  Returns a list of result dicts (same keys as align(), plus 'status')."""
-        scans = [np.ascontiguousarray(a, dtype=np.float32)[:, :3] for a in scans]
+        self.set_batch_sources(scans)
+        return self.align_batch_resident(guesses, pair_scan)
+
+    def set_batch_sources(self, scans):
+        """Upload the scans of an offline-replay batch once; they stay resident for align_batch_resident()."""
+        scans = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)[:, :3]) for a in scans]
         pts = np.ascontiguousarray(np.concatenate(scans)) if scans else np.zeros((0, 3), np.float32)
         off = np.zeros(len(scans) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in scans])
+        self._chk(lib().ndt_set_batch_sources(self._h, pts.ctypes.data, 12, off.ctypes.data, len(scans)))
+
+    def align_batch_resident(self, guesses, pair_scan=None):
         g = np.ascontiguousarray(np.stack([_T(T) for T in guesses]))
         n_pairs = len(g)
         ps = None if pair_scan is None else np.ascontiguousarray(pair_scan, dtype=np.int32)
         res = (Result * n_pairs)()
-        self._chk(lib().ndt_align_batch(self._h, pts.ctypes.data, 12, off.ctypes.data, len(scans),
-                                        None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data, res))
+        self._chk(lib().ndt_align_batch_resident(self._h, None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data, res))
         return [dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6),
                      b=np.array(r.b), chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations,
                      converged=bool(r.converged), last_dx_norm=r.last_dx_norm) for r in res]
@@ -263,6 +273,12 @@ class NDT:
         t = _T(T); us = C.c_double()
         self._chk(lib().ndt_time_residual(self._h, t.ctypes.data, int(reps), C.addressof(us)))
         return us.value
+
+    def time_residual_batch(self, reps=100):
+        """(us per launch, points per launch, hits per point) of the batched residual kernel on the resident batch."""
+        us = C.c_double(); pts = C.c_double(); hp = C.c_double()
+        self._chk(lib().ndt_time_residual_batch(self._h, int(reps), C.addressof(us), C.addressof(pts), C.addressof(hp)))
+        return us.value, pts.value, hp.value
 
     def synchronize(self): self._chk(lib().ndt_synchronize(self._h))
 

@@ -70,6 +70,8 @@ struct ndt_handle {
     DevBuf comm_rows;            // [2][ACC_N] doubles: all-reduce send / receive rows
     // offline replay batch
     DevBuf braw, bx, by, bz, boff, bpair, bstates, bpartials, bdone;
+    std::vector<int64_t> b_offsets; int64_t b_max_pts = 0;
+    size_t b_pairs = 0; int b_rows = 0; bool b_has_pair_scan = false; double b_points = 0;   // geometry of the resident batch
 };
 
 #define H_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
@@ -383,13 +385,9 @@ void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz) {
     if (iz) *iz = c;
 }
 
-int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t* scan_offsets, size_t n_scans,
-                    const int32_t* pair_scan, size_t n_pairs, const double* guesses, ndt_result* results) {
+int ndt_set_batch_sources(ndt_handle* h, const void* pts, size_t stride, const int64_t* scan_offsets, size_t n_scans) {
     if (!h) return NDT_ERR_INVALID_ARG;
-    if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
-    if (!scan_offsets || !n_scans || !n_pairs || !guesses || !results || stride < 12 || (stride & 3)) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
-    if (!pair_scan && n_pairs != n_scans) { h->err = "without pair_scan there must be one scan per pair"; return NDT_ERR_INVALID_ARG; }
-    if (h->comm) { h->err = "batched replay has no collective: destroy the communicator first"; return NDT_ERR_INVALID_ARG; }
+    if (!scan_offsets || !n_scans || stride < 12 || (stride & 3)) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
     int64_t max_pts = 0;
     for (size_t i = 0; i < n_scans; ++i) {
         const int64_t m = scan_offsets[i + 1] - scan_offsets[i];
@@ -398,12 +396,8 @@ int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t
     }
     const size_t total = (size_t)scan_offsets[n_scans];
     if ((total && !pts) || max_pts >= (1ll << 31)) { h->err = "bad point buffer"; return NDT_ERR_INVALID_ARG; }
-    if (pair_scan)
-        for (size_t p = 0; p < n_pairs; ++p)
-            if (pair_scan[p] < 0 || (size_t)pair_scan[p] >= n_scans) { h->err = "pair_scan out of range"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = h->stream;
-    // upload: scans (AoS -> SoA), offsets, pair table, initial states
     H_TRY(h->braw.ensure(total * stride + 16));
     H_TRY(h->bx.ensure(total * 4 + 16)); H_TRY(h->by.ensure(total * 4 + 16)); H_TRY(h->bz.ensure(total * 4 + 16));
     if (total) {
@@ -412,6 +406,28 @@ int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t
     }
     H_TRY(h->boff.ensure((n_scans + 1) * 8));
     H_TRY(hipMemcpyAsync(h->boff.p, scan_offsets, (n_scans + 1) * 8, hipMemcpyHostToDevice, s));
+    H_TRY(hipStreamSynchronize(s));           // the caller's buffers are free again
+    h->b_offsets.assign(scan_offsets, scan_offsets + n_scans + 1);
+    h->b_max_pts = max_pts;
+    h->b_pairs = 0;
+    return NDT_OK;
+}
+
+int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_pairs, const double* guesses, ndt_result* results) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
+    if (h->b_offsets.size() < 2) { h->err = "no batch sources: call ndt_set_batch_sources first"; return NDT_ERR_NO_SOURCE; }
+    const size_t n_scans = h->b_offsets.size() - 1;
+    const int64_t* scan_offsets = h->b_offsets.data();
+    const int64_t max_pts = h->b_max_pts;
+    if (!n_pairs || !guesses || !results) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
+    if (!pair_scan && n_pairs != n_scans) { h->err = "without pair_scan there must be one scan per pair"; return NDT_ERR_INVALID_ARG; }
+    if (h->comm) { h->err = "batched replay has no collective: destroy the communicator first"; return NDT_ERR_INVALID_ARG; }
+    if (pair_scan)
+        for (size_t p = 0; p < n_pairs; ++p)
+            if (pair_scan[p] < 0 || (size_t)pair_scan[p] >= n_scans) { h->err = "pair_scan out of range"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = h->stream;
     if (pair_scan) {
         H_TRY(h->bpair.ensure(n_pairs * 4));
         H_TRY(hipMemcpyAsync(h->bpair.p, pair_scan, n_pairs * 4, hipMemcpyHostToDevice, s));
@@ -424,8 +440,11 @@ int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
-    H_TRY(hipStreamSynchronize(s));           // the caller's buffers (and st) are free again
+    H_TRY(hipStreamSynchronize(s));           // pair_scan and st are free again
 
+    h->b_pairs = n_pairs; h->b_rows = rows; h->b_has_pair_scan = pair_scan != nullptr;
+    h->b_points = 0;
+    for (size_t p = 0; p < n_pairs; ++p) { const size_t sc = pair_scan ? (size_t)pair_scan[p] : p; h->b_points += (double)(scan_offsets[sc + 1] - scan_offsets[sc]); }
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     GnState* dst = h->bstates.as<GnState>();
@@ -475,6 +494,13 @@ int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t
         out->status = loop[p].status;
     }
     return NDT_OK;
+}
+
+int ndt_align_batch(ndt_handle* h, const void* pts, size_t stride, const int64_t* scan_offsets, size_t n_scans,
+                    const int32_t* pair_scan, size_t n_pairs, const double* guesses, ndt_result* results) {
+    int rc = ndt_set_batch_sources(h, pts, stride, scan_offsets, n_scans);
+    if (rc != NDT_OK) return rc;
+    return ndt_align_batch_resident(h, pair_scan, n_pairs, guesses, results);
 }
 
 int ndt_comm_unique_id(char id_out[128]) {
@@ -538,6 +564,41 @@ int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_pe
     H_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *us_per_launch = 1e3 * (double)ms / reps;
+    return NDT_OK;
+}
+
+int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, double* points_per_launch, double* hits_per_point) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->b_pairs || h->b_pairs > 32768 || reps < 1 || !us_per_launch) { h->err = "no resident batch (call ndt_align_batch first; at most 32768 pairs)"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
+    const EvalParams ep = eval_params(h);
+    const SolveParams sp = solve_params(h);
+    auto pass = [&]() {
+        launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(),
+                              h->b_has_pair_scan ? h->bpair.as<int32_t>() : nullptr, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
+                              h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, 0, (int)h->b_pairs, 1, h->stream);
+    };
+    for (int i = 0; i < 3; ++i) pass();
+    H_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) pass();
+    H_TRY(hipEventRecord(e1, h->stream));
+    H_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    H_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_per_launch = 1e3 * (double)ms / reps;
+    if (points_per_launch) *points_per_launch = h->b_points;
+    if (hits_per_point) {   // measured at the poses the batch ended at
+        launch_reduce_solve_batch(h->bpartials.as<double>(), h->b_rows, h->bstates.as<GnState>(), (int)h->b_pairs, sp, 0, 1, h->bdone.as<int32_t>(), h->stream);
+        std::vector<GnState> st(h->b_pairs);
+        H_TRY(hipMemcpyAsync(st.data(), h->bstates.p, h->b_pairs * sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipStreamSynchronize(h->stream));
+        double hits = 0;
+        for (auto& g : st) hits += g.acc[ACC_HITS];
+        *hits_per_point = h->b_points > 0 ? hits / h->b_points : 0.0;
+    }
     return NDT_OK;
 }
 
