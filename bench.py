@@ -107,7 +107,8 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         # rendezvous / barriers / timing reductions on CPU tensors (gloo); the data-path collective, where the
         # mode has one, is RCCL inside libndt_mi355.so on the handle's own stream
         import torch
@@ -116,22 +117,22 @@ def main():
     import lio_slam_amd as la
     from lio_slam_amd import synth
 
-    w = load_workload(2, rank, world, dist, a.small)
+    w = load_workload(2, rank, world if use_dist else 1, dist, a.small)
     ndt = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
 
     def barrier():
         ndt.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def allmax(x):
-        if world == 1:
+        if not use_dist:
             return x
         import torch
         t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); return float(t[0])
 
     def allsum(x):
-        if world == 1:
+        if not use_dist:
             return x
         import torch
         t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t); return float(t[0])
@@ -173,7 +174,7 @@ def main():
         from lio_slam_amd.shard import shard_range
         scan_all, guess = w["scan"], w["guess"]
         lo, hi = shard_range(len(scan_all), rank, world)
-        if world > 1:
+        if use_dist:
             ids = [la.NDT.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             ndt.comm_init(rank, world, ids[0])
@@ -250,7 +251,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ndt.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
