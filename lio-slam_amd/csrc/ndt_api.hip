@@ -155,8 +155,7 @@ static int merge_common(ndt_handle* h, const void* pts, size_t n, size_t stride,
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
     if (reset || !h->have_target) {
-        H_TRY(hipStreamSynchronize(h->stream));
-        map_free(h->map);
+        H_TRY(map_clear(h->map, h->stream));
         h->build_cfg.kp = key_params(h->cfg);
         h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
         h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;

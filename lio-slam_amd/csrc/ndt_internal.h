@@ -49,10 +49,11 @@ struct MapBuildCfg {
 // ---- ndt_map.hip
 hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s);
 void map_free(VoxelMap& m);
+hipError_t map_clear(VoxelMap& m, hipStream_t s);
 struct MapWork {
-    DevBuf raw, tx, ty, tz, keys_a, keys_b, vals_a, vals_b, hist, flags, segid, seg_start, scan_tmp, misc;
+    DevBuf raw, tx, ty, tz, gx, gy, gz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, segid, seg_start, scan_tmp, misc;
     void release() {
-        DevBuf* all[] = {&raw, &tx, &ty, &tz, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &segid, &seg_start, &scan_tmp, &misc};
+        DevBuf* all[] = {&raw, &tx, &ty, &tz, &gx, &gy, &gz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &segid, &seg_start, &scan_tmp, &misc};
         for (DevBuf* b : all) b->release();
     }
 };

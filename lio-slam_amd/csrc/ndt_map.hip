@@ -39,6 +39,15 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     k_init_slots<<<(unsigned)((cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, cap);
     return hipGetLastError();
 }
+// empties the table in place (keeps the allocation: a rebuild of a same-sized map allocates nothing)
+hipError_t map_clear(VoxelMap& m, hipStream_t s) {
+    if (!m.cap) return hipSuccess;
+    hipError_t e = hipMemsetAsync(m.d_n_vox, 0, 256, s);
+    if (e != hipSuccess) return e;
+    m.n_vox = 0;
+    k_init_slots<<<(unsigned)((m.cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.cap);
+    return hipGetLastError();
+}
 void map_free(VoxelMap& m) {
     if (m.slots) (void)hipFree(m.slots);
     if (m.keys) (void)hipFree(m.keys);
@@ -65,15 +74,18 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 // ------------------------------------------------------------------ pass 1: world point, packed key, bbox
 
 // misc layout (int32): [0..2] min cell, [3..5] max cell, [6] n_valid, [7] nseg
-__global__ void k_target_keys(const unsigned char* raw, size_t n, size_t stride, int has_T, const double* Rt,
-                              KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
-                              int32_t* misc) {
+// Same-address global atomics from thousands of blocks serialise (~11 ns each), so every block writes one row
+// of partials and a single block folds the rows.
+#define TK_MAX_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, size_t n, size_t stride, int has_T, const double* Rt,
+                                                     KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
+                                                     int32_t* block_rows) {
     __shared__ int32_t smn[3], smx[3], scnt;
     if (threadIdx.x < 3) { smn[threadIdx.x] = INT32_MAX; smx[threadIdx.x] = INT32_MIN; }
     if (threadIdx.x == 0) scnt = 0;
     __syncthreads();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    int32_t okc = 0, mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float* p = (const float*)(raw + i * stride);
         float x = p[0], y = p[1], z = p[2];
         bool ok = isfinite(x) && isfinite(y) && isfinite(z);
@@ -88,14 +100,57 @@ __global__ void k_target_keys(const unsigned char* raw, size_t n, size_t stride,
         vals[i] = (uint32_t)i;
         keys[i] = ok ? ndt_pack(c[0], c[1], c[2]) : NDT_KEY_EMPTY;
         if (ok) {
-            atomicAdd(&scnt, 1);
+            okc += 1;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { atomicMin(&smn[j], c[j]); atomicMax(&smx[j], c[j]); }
+            for (int j = 0; j < 3; ++j) { mn[j] = min(mn[j], c[j]); mx[j] = max(mx[j], c[j]); }
         }
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        okc += __shfl_xor(okc, o);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { mn[j] = min(mn[j], __shfl_xor(mn[j], o)); mx[j] = max(mx[j], __shfl_xor(mx[j], o)); }
+    }
+    if ((threadIdx.x & 63) == 0 && okc) {
+        atomicAdd(&scnt, okc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { atomicMin(&smn[j], mn[j]); atomicMax(&smx[j], mx[j]); }
+    }
     __syncthreads();
-    if (threadIdx.x < 3 && scnt) { atomicMin(&misc[threadIdx.x], smn[threadIdx.x]); atomicMax(&misc[3 + threadIdx.x], smx[threadIdx.x]); }
-    if (threadIdx.x == 0 && scnt) atomicAdd(&misc[6], scnt);
+    int32_t* row = block_rows + (size_t)blockIdx.x * 8;
+    if (threadIdx.x < 3) { row[threadIdx.x] = smn[threadIdx.x]; row[3 + threadIdx.x] = smx[threadIdx.x]; }
+    if (threadIdx.x == 0) { row[6] = scnt; row[7] = 0; }
+}
+__global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* block_rows, int nrows, int32_t* misc) {
+    __shared__ int32_t sm[TK_MAX_BLOCKS / 64][8];
+    int32_t v[7] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0};
+    if ((int)threadIdx.x < nrows) {
+        const int32_t* row = block_rows + (size_t)threadIdx.x * 8;
+        if (row[6]) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = row[j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { v[j] = min(v[j], __shfl_xor(v[j], o)); v[3 + j] = max(v[3 + j], __shfl_xor(v[3 + j], o)); }
+        v[6] += __shfl_xor(v[6], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) sm[threadIdx.x >> 6][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        int32_t r = sm[0][threadIdx.x];
+        for (int w = 1; w < TK_MAX_BLOCKS / 64; ++w) {
+            const int32_t x = sm[w][threadIdx.x];
+            r = threadIdx.x < 3 ? min(r, x) : threadIdx.x < 6 ? max(r, x) : r + x;
+        }
+        misc[threadIdx.x] = r;
+    }
+    if (threadIdx.x == 7) misc[7] = 0;
 }
 
 // pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
@@ -326,12 +381,21 @@ __device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3],
     sl->valid = valid;
 }
 
-#define SEG_LANES 8
-// One 8-lane group per segment (= one voxel of the batch): strided sums in voxel-local float64 coordinates,
-// xor-tree over the 8 lanes, then lane 0 claims / finds the hash slot, merges and finalises.
-__global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* sv, const uint32_t* seg_start, uint32_t nseg,
+// world points gathered into sorted order, so the per-voxel sums read contiguous lanes
+__global__ void k_gather_sorted(const uint32_t* sv, size_t n, const float* tx, const float* ty, const float* tz, float* gx, float* gy, float* gz) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t idx = sv[i];
+    gx[i] = tx[idx]; gy[i] = ty[idx]; gz[i] = tz[idx];
+}
+
+// One SEG_LANES-lane group per segment (= one voxel of the batch): strided sums in voxel-local float64
+// coordinates over the sorted points, xor-tree over the group, then lane 0 claims / finds the hash slot, merges
+// and finalises.  SEG_LANES is 8 for sparse batches and 64 (a whole wave) when voxels hold many points.
+template <int SEG_LANES>
+__global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg,
                                                        const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
-                                                       VoxSlot* slots, int64_t* keys, double* mean, double* cov, uint64_t mask, int32_t* n_vox) {
+                                                       VoxSlot* slots, int64_t* keys, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag) {
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     bool act = g < nseg;
@@ -348,8 +412,7 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     }
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = s + l; i < e; i += SEG_LANES) {
-        uint32_t idx = sv[i];
-        double d0 = (double)tx[idx] - org[0], d1 = (double)ty[idx] - org[1], d2 = (double)tz[idx] - org[2];
+        double d0 = (double)tx[i] - org[0], d1 = (double)ty[i] - org[1], d2 = (double)tz[i] - org[2];
         a[0] += d0; a[1] += d1; a[2] += d2;
         a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
         a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
@@ -381,8 +444,8 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     double* mp = mean + slot * 3;
     double* cp = cov + slot * 6;
     int32_t ntot = nb;
+    fresh_flag[g] = fresh ? 1u : 0u;    // summed afterwards: a same-address atomic per new voxel would serialise
     if (fresh) {
-        atomicAdd(n_vox, 1);
         sl->key = key;
         if (slot < 4) keys[mask + 1 + slot] = key;   // mirror entries
     } else {        // UpdateMeanAndCov (math_utils.h:87-98)
@@ -436,14 +499,14 @@ static size_t pow2_at_least(size_t v) { size_t c = 1024; while (c < v) c <<= 1; 
 
 static int map_reserve(VoxelMap& m, size_t want_voxels, hipStream_t s, std::string& err) {
     size_t need = pow2_at_least(want_voxels * 2);       // load factor <= 1/2
-    if (m.cap >= need) return NDT_OK;
+    if (m.cap >= need && !(m.n_vox == 0 && m.cap > 16 * need)) return NDT_OK;   // an empty, far too large table is re-made
+    if (m.n_vox == 0 && m.cap) { HIP_TRY(hipStreamSynchronize(s)); map_free(m); }
     size_t ncap = pow2_at_least(want_voxels * 4);        // grow with headroom
     VoxelMap nm;
     HIP_TRY(map_alloc(nm, ncap, s));
     if (m.cap) {
         k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.mean, nm.cov, ncap - 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(nm.d_n_vox, m.d_n_vox, 4, hipMemcpyDeviceToDevice, s));
         nm.n_vox = m.n_vox;
         HIP_TRY(hipStreamSynchronize(s));
         map_free(m);
@@ -475,8 +538,11 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         HIP_TRY(hipMemcpyAsync(dRt, Rt, sizeof Rt, hipMemcpyHostToDevice, s));
     }
     const unsigned nb256 = (unsigned)((n + 255) / 256);
-    k_target_keys<<<nb256, 256, 0, s>>>((const unsigned char*)w.raw.p, n, stride, R ? 1 : 0, dRt, cfg.kp, w.tx.as<float>(), w.ty.as<float>(),
-                                        w.tz.as<float>(), w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.misc.as<int32_t>());
+    const unsigned nb_tk = std::min<unsigned>(nb256, TK_MAX_BLOCKS);
+    HIP_TRY(w.block_rows.ensure((size_t)TK_MAX_BLOCKS * 8 * 4));
+    k_target_keys<<<nb_tk, 256, 0, s>>>((const unsigned char*)w.raw.p, n, stride, R ? 1 : 0, dRt, cfg.kp, w.tx.as<float>(), w.ty.as<float>(),
+                                        w.tz.as<float>(), w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+    k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>());
     HIP_TRY(hipGetLastError());
     int32_t misc[8];
     HIP_TRY(hipMemcpyAsync(misc, w.misc.p, sizeof misc, hipMemcpyDeviceToHost, s));
@@ -526,14 +592,29 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
 
     int rc = map_reserve(m, (size_t)m.n_vox + nseg, s, err);
     if (rc != NDT_OK) return rc;
-    const unsigned nbs = (unsigned)(((size_t)nseg * SEG_LANES + 255) / 256);
-    k_segment_merge<<<nbs, 256, 0, s>>>(ka, va, w.seg_start.as<uint32_t>(), nseg, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), km, cfg,
-                                        m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), m.d_n_vox);
+    HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
+    k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
+    if (n_valid / nseg >= 24) {
+        const unsigned nbs = (unsigned)(((size_t)nseg * 64 + 255) / 256);
+        k_segment_merge<64><<<nbs, 256, 0, s>>>(ka, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), km, cfg,
+                                                m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+    } else {
+        const unsigned nbs = (unsigned)(((size_t)nseg * 8 + 255) / 256);
+        k_segment_merge<8><<<nbs, 256, 0, s>>>(ka, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), km, cfg,
+                                               m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+    }
     HIP_TRY(hipGetLastError());
-    int32_t nv = 0;
-    HIP_TRY(hipMemcpyAsync(&nv, m.d_n_vox, 4, hipMemcpyDeviceToHost, s));
+    // new voxels = sum of the fresh flags (block sums + one-block spine; no scan-down needed)
+    {
+        const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
+        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(w.flags.as<uint32_t>(), nseg, w.scan_tmp.as<uint32_t>());
+        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, d_nseg);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t n_new = 0;
+    HIP_TRY(hipMemcpyAsync(&n_new, d_nseg, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    m.n_vox = nv;
+    m.n_vox += n_new;
     return NDT_OK;
 }
 
