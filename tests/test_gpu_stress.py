@@ -1,0 +1,78 @@
+"""Stress cases for the voxel hash and the upload path: dense random maps (long probe chains, table growth over
+several merges), ragged inputs (non-finite points, 16-byte records, device-resident buffers)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_cloud(rng, n_cells=(48, 48, 12), per_cell=8, origin=(-20.0, 7.0, -3.0)):
+    cells = np.stack(np.meshgrid(*[np.arange(k) for k in n_cells], indexing="ij"), -1).reshape(-1, 3)
+    pts = (cells[:, None, :] + rng.uniform(0.05, 0.95, (len(cells), per_cell, 3))).reshape(-1, 3) + np.array(origin)
+    return rng.permutation(pts).astype(np.float32)
+
+
+def test_dense_random_map_growth_and_chains():
+    import lio_slam_amd as la
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(21)
+    m = _dense_cloud(rng)                                   # 27 648 voxels x 8 points, every voxel valid
+    n = la.NDT(); o = Oracle()
+    parts = np.array_split(m, 5)
+    n.set_target(parts[0]); o.set_target(parts[0])
+    for p in parts[1:]:                                      # the table grows (rehash) more than once
+        n.add_target(p); o.add_target(p)
+    vg, vo = n.export_voxels(), o.export_voxels()
+    assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"])
+    assert np.array_equal(vg["valid"], vo["valid"]) and len(vg["keys"]) >= 27000
+    np.testing.assert_allclose(vg["mean"], vo["mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vg["cov"], vo["cov"], rtol=1e-7, atol=1e-12)
+    s = (rng.uniform(0, 1, (60000, 3)) * np.array([50, 50, 14]) + np.array([-21.0, 6.0, -4.0])).astype(np.float32)
+    n.set_source(s); o.set_source(s)
+    T = np.eye(4); T[:3, 3] = [0.013, -0.021, 0.008]
+    for nearby in (7, 1):
+        n.configure(nearby=nearby); o.set_params(nearby=nearby)
+        kg, mg = n.source_cells(T); ko, mo = o.source_cells(T)
+        assert np.array_equal(kg, ko) and np.array_equal(mg, mo)
+        eg, eo = n.eval(T), o.eval(T)
+        assert eg["n_effective"] == eo["n_effective"] and eo["n_effective"] > 10000
+        assert rel_err(eg["H"], eo["H"]) < 1e-5 and rel_err(eg["b"], eo["b"]) < 1e-5
+
+
+def test_ragged_inputs_device_pointers_and_strides():
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    from oracle.oracle import Oracle
+    c = synth.make_config(0)
+    rng = np.random.default_rng(4)
+    scan = c["scan"].copy()
+    bad = rng.choice(len(scan), 500, replace=False)
+    scan[bad[:250], rng.integers(0, 3, 250)] = np.nan           # the simulator's organised clouds hold NaN points
+    scan[bad[250:], rng.integers(0, 3, 250)] = np.inf
+    scan[0] = [3e6, 0, 0]                                        # finite but outside the 21-bit key range
+    m16 = np.zeros((len(c["map"]), 4), np.float32); m16[:, :3] = c["map"]; m16[:, 3] = 7.0    # 16-byte records
+    o = Oracle(); o.set_target(c["map"]); o.set_source(scan)
+    n = la.NDT(); n.set_target(m16)
+    # source handed over as a device pointer (hipMalloc'd by the caller), 32-byte slam_czc::Point records
+    hip = ctypes.CDLL("libamdhip64.so")
+    rec = synth.to_point32(scan)
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(rec.nbytes)) == 0
+    assert hip.hipMemcpy(dptr, ctypes.c_void_p(rec.ctypes.data), ctypes.c_size_t(rec.nbytes), 1) == 0
+    n.set_source((dptr.value, len(rec), 32))
+    assert hip.hipFree(dptr) == 0                                # the engine copied: the caller's buffer is free
+    kg, mg = n.source_cells(c["guess"]); ko, mo = o.source_cells(c["guess"])
+    fin = np.isfinite(scan).all(axis=1)
+    assert np.all(kg[~fin] == np.iinfo(np.int64).min) and kg[0] == np.iinfo(np.int64).min
+    assert np.array_equal(kg[fin], ko) and np.array_equal(mg[fin], mo)     # the oracle drops non-finite points
+    eg, eo = n.eval(c["guess"]), o.eval(c["guess"])
+    assert eg["n_effective"] == eo["n_effective"]
+    assert rel_err(eg["H"], eo["H"]) < 1e-5 and rel_err(eg["b"], eo["b"]) < 1e-5
+    with pytest.raises(la.NdtError):
+        n.set_source((0, 10, 12))                                # null buffer
+    with pytest.raises(la.NdtError):
+        n.set_target((1, 10, 10))                                # stride not a multiple of 4 / below 12
