@@ -435,7 +435,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     for (size_t p = 0; p < n_pairs; ++p) state_from_T(&st[p], guesses + 16 * p);
     H_TRY(h->bstates.ensure(n_pairs * sizeof(GnState)));
     H_TRY(hipMemcpyAsync(h->bstates.p, st.data(), n_pairs * sizeof(GnState), hipMemcpyHostToDevice, s));
-    const int rows = residual_grid((size_t)max_pts);
+    const int rows = residual_grid((size_t)max_pts, n_pairs);
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));

@@ -68,7 +68,7 @@ int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& key
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
 
 // ---- ndt_residual.hip
-int residual_grid(size_t n);
+int residual_grid(size_t n, size_t problems = 1);
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, hipStream_t s);

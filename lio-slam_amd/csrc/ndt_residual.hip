@@ -274,8 +274,15 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
     block_store_row(acc, partials + ((size_t)pair * rows_per_pair + blockIdx.x) * ACC_N);
 }
 
-int residual_grid(size_t n) {
-    size_t g = (n + RES_THREADS - 1) / RES_THREADS;
+// Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
+// the whole launch is small (latency-bound: every wave should be resident at once); up to 8 points per lane once
+// there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
+int residual_grid(size_t n, size_t problems) {
+    const size_t total = n * (problems ? problems : 1);
+    size_t ppt = total / ((size_t)4096 * 64);        // keep >= ~4 waves per SIMD
+    if (ppt < 1) ppt = 1;
+    if (ppt > 8) ppt = 8;
+    size_t g = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
     return (int)g;
