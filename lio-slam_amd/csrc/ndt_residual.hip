@@ -16,7 +16,8 @@
 // Bound: HBM/L2 gather (12 + 8K + 40h algorithmic bytes per point); no MFMA.
 #include "ndt_internal.h"
 
-#define RES_THREADS 256
+#define RES_THREADS 256    // batched launches: several blocks per CU overlap their tails
+#define RES1_THREADS 512   // single-problem launches: one block per CU, half as many rows to reduce
 #define SLOT_NONE 0xFFFFFFFFu
 
 struct Pose { double R[9]; double t[3]; };
@@ -201,24 +202,29 @@ __device__ __forceinline__ double wave_reduce_scatter32(double* acc) {
 }
 
 // rows: partials[blockIdx.x][32]
+template <int THREADS>
 __device__ __forceinline__ void block_store_row(double* acc, double* __restrict__ row_out) {
-    __shared__ double sm[RES_THREADS / 64][ACC_N];
+    __shared__ double sm[THREADS / 64][ACC_N];
     const double v = wave_reduce_scatter32(acc);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (!(lane & 1)) sm[w][lane >> 1] = v;
     __syncthreads();
-    if (threadIdx.x < ACC_N)
-        row_out[threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    if (threadIdx.x < ACC_N) {
+        double v = sm[0][threadIdx.x];
+#pragma unroll
+        for (int j = 1; j < THREADS / 64; ++j) v += sm[j][threadIdx.x];
+        row_out[threadIdx.x] = v;
+    }
 }
 
 template <int K, bool CELLS>
-__global__ __launch_bounds__(RES_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
+__global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
                                                           const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
                                                           const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st,
                                                           EvalParams ep, double* __restrict__ partials, int force, int64_t* keys_out,
                                                           uint8_t* mask_out) {
     // the first point's coordinates are requested before the state is read, so the two misses overlap
-    int i = blockIdx.x * RES_THREADS + threadIdx.x;
+    int i = blockIdx.x * RES1_THREADS + threadIdx.x;
     float xf = 0.f, yf = 0.f, zf = 0.f;
     if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     if (!force && st->done) return;
@@ -234,10 +240,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(const float* __restric
         int64_t ck;
         const unsigned hm = point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         if (CELLS) { keys_out[i] = ck; mask_out[i] = (uint8_t)hm; }
-        i += gridDim.x * RES_THREADS;
+        i += gridDim.x * RES1_THREADS;
         if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     }
-    block_store_row(acc, partials + (size_t)blockIdx.x * ACC_N);
+    block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
@@ -271,14 +277,18 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
         i += (int64_t)gridDim.x * RES_THREADS;
         if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     }
-    block_store_row(acc, partials + ((size_t)pair * rows_per_pair + blockIdx.x) * ACC_N);
+    block_store_row<RES_THREADS>(acc, partials + ((size_t)pair * rows_per_pair + blockIdx.x) * ACC_N);
 }
 
 // Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
 // the whole launch is small (latency-bound: every wave should be resident at once); up to 8 points per lane once
 // there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
 int residual_grid(size_t n, size_t problems) {
-    const size_t total = n * (problems ? problems : 1);
+    if (problems <= 1) {                              // k_residual: 512-thread blocks, one point per lane up to 2048 blocks
+        size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
+        return (int)(g < 1 ? 1 : g > 2048 ? 2048 : g);
+    }
+    const size_t total = n * problems;
     size_t ppt = total / ((size_t)4096 * 64);        // keep >= ~4 waves per SIMD
     if (ppt < 1) ppt = 1;
     if (ppt > 8) ppt = 8;
@@ -291,7 +301,7 @@ int residual_grid(size_t n, size_t problems) {
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, hipStream_t s) {
-#define LAUNCH(KK, CC) k_residual<KK, CC><<<grid, RES_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st, ep, partials, force, keys_out, mask_out)
+#define LAUNCH(KK, CC) k_residual<KK, CC><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st, ep, partials, force, keys_out, mask_out)
     if (ep.nearby == 7) { if (keys_out) LAUNCH(7, true); else LAUNCH(7, false); }
     else { if (keys_out) LAUNCH(1, true); else LAUNCH(1, false); }
 #undef LAUNCH
@@ -412,8 +422,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
     __shared__ double sm[32][ACC_N + 1];
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
+    const int done = st->done;
     reduce_rows<32>(partials, n_partials, sm, true);
-    if (!force && st->done) return;
+    if (!force && done) return;
     if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
     if (do_solve && threadIdx.x == 0) {
         double acc[ACC_N];
