@@ -116,6 +116,18 @@ int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes
 /* ndt_.setInputSource(pc_trans_filter) (process.cc:87). */
 int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
 
+/* Scan pre-processing on the device, so a LiDAR frame crosses PCIe once:
+ * pcl::transformPointCloud(LiDAR->IMU extrinsic) + pcl::VoxelGrid(leaf).filter() of src/slam/src/process.cc:62-73,
+ * then setInputSource (process.cc:87).  T may be NULL (no transform).  One centroid (xyz only) per occupied leaf
+ * cell, cells in PCL's index order (x fastest, z slowest); non-finite points are skipped as PCL does. */
+int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes, float leaf,
+                               const double T[16]);
+/* Reads the resident source back as packed xyz (xyz may be NULL to ask for the size only). */
+int ndt_get_source(ndt_handle* h, float* xyz, size_t cap_points, size_t* n_out);
+/* The keyframe step of process.cc:134-147 without a host round trip: the resident source, transformed by T, is
+ * merged into the resident map (what `*pc_key_ += *output; setInputTarget(pc_key_)` does with pc_trans_filter). */
+int ndt_add_target_from_source(ndt_handle* h, const double T[16]);
+
 /* ndt_.align(*output, guess) + getFinalTransformation() (process.cc:94-95).
  * Returns NDT_OK also when the iteration cap was hit (out->converged == 0),
  * as the reference never checks convergence. */

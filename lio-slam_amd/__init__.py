@@ -22,7 +22,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
-    "ndt_set_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
+    "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
@@ -80,6 +80,9 @@ def lib():
     L.ndt_set_target.argtypes = [vp, vp, sz, sz]
     L.ndt_add_target.argtypes = [vp, vp, sz, sz, vp]
     L.ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.ndt_set_source_downsampled.argtypes = [vp, vp, sz, sz, C.c_float, vp]
+    L.ndt_get_source.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.ndt_add_target_from_source.argtypes = [vp, vp]
     L.ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
     L.ndt_eval.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ndt_source_cells.argtypes = [vp, vp, vp, vp, sz]
@@ -189,6 +192,22 @@ class NDT:
     def set_source(self, pts):
         keep, p, n, s = _points(pts)
         self._chk(lib().ndt_set_source(self._h, p, n, s))
+
+    def set_source_downsampled(self, pts, leaf=0.5, T=None):
+        """process.cc:62-73 + 87 on the device: extrinsic transform, VoxelGrid(leaf) centroids, set as the source."""
+        keep, p, n, s = _points(pts)
+        t = None if T is None else _T(T)
+        self._chk(lib().ndt_set_source_downsampled(self._h, p, n, s, float(leaf), None if t is None else t.ctypes.data))
+
+    def get_source(self):
+        n = self.source_size()
+        out = np.zeros((n, 3), np.float32); no = C.c_size_t()
+        self._chk(lib().ndt_get_source(self._h, out.ctypes.data, n, C.byref(no)))
+        return out
+
+    def add_target_from_source(self, T=None):
+        t = None if T is None else _T(T)
+        self._chk(lib().ndt_add_target_from_source(self._h, None if t is None else t.ctypes.data))
 
     setInputTarget, setInputSource = set_target, set_source
 

@@ -164,7 +164,7 @@ static int merge_common(ndt_handle* h, const void* pts, size_t n, size_t stride,
     if (T) {
         for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; }
     }
-    int rc = map_merge_points(h->map, h->work, h->build_cfg, pts, n, stride, T ? R : nullptr, T ? t : nullptr, h->stream,
+    int rc = map_merge_points(h->map, h->work, h->build_cfg, pts, nullptr, nullptr, n, stride, T ? R : nullptr, T ? t : nullptr, h->stream,
                               &h->last_radix_passes, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;
@@ -191,6 +191,62 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
     h->n_src = n;
     h->have_source = true;
     return NDT_OK;
+}
+
+// ---- scan pre-processing on the device
+
+int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t stride, float leaf, const double T[16]) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
+    if (!(leaf > 0.f) || !isfinite(leaf)) { h->err = "leaf size must be positive"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    KeyParams kp;
+    kp.inv_leaf_f32 = 1.0f / leaf; kp.inv_res_d = (double)kp.inv_leaf_f32; kp.res_d = (double)leaf; kp.key_rule = NDT_KEY_FLOOR_F32;
+    double R[9], t[3];
+    if (T) { for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; } }
+    size_t n_out = 0;
+    int rc = downsample_points(h->work, kp, pts, n, stride, T ? R : nullptr, T ? t : nullptr, h->sx, h->sy, h->sz, &n_out, h->stream, h->err);
+    if (rc != NDT_OK) return rc;
+    H_TRY(h->partials.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
+    H_TRY(hipStreamSynchronize(h->stream));
+    h->n_src = n_out;
+    h->have_source = true;
+    return NDT_OK;
+}
+
+int ndt_get_source(ndt_handle* h, float* xyz, size_t cap, size_t* n_out) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (n_out) *n_out = h->n_src;
+    if (!h->have_source) { h->err = "no source"; return NDT_ERR_NO_SOURCE; }
+    if (!xyz) return NDT_OK;
+    if (cap < h->n_src) { h->err = "output buffer smaller than the source"; return NDT_ERR_CAPACITY; }
+    if (!h->n_src) return NDT_OK;
+    H_TRY(hipSetDevice(h->cfg.device));
+    std::vector<float> tmp(h->n_src * 3);
+    H_TRY(hipMemcpyAsync(tmp.data(), h->sx.p, h->n_src * 4, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipMemcpyAsync(tmp.data() + h->n_src, h->sy.p, h->n_src * 4, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipMemcpyAsync(tmp.data() + 2 * h->n_src, h->sz.p, h->n_src * 4, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->n_src; ++i) { xyz[3 * i] = tmp[i]; xyz[3 * i + 1] = tmp[h->n_src + i]; xyz[3 * i + 2] = tmp[2 * h->n_src + i]; }
+    return NDT_OK;
+}
+
+int ndt_add_target_from_source(ndt_handle* h, const double T[16]) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    if (!h->have_target) {
+        H_TRY(map_clear(h->map, h->stream));
+        h->build_cfg.kp = key_params(h->cfg);
+        h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
+        h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+    }
+    double R[9], t[3];
+    if (T) { for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; } }
+    int rc = map_merge_points(h->map, h->work, h->build_cfg, h->sx.p, h->sy.as<float>(), h->sz.as<float>(), h->n_src, 0, T ? R : nullptr,
+                              T ? t : nullptr, h->stream, &h->last_radix_passes, h->err);
+    if (rc == NDT_OK) h->have_target = true;
+    return rc;
 }
 
 int64_t ndt_source_size(const ndt_handle* h) { return h ? (int64_t)h->n_src : 0; }

@@ -35,9 +35,17 @@ struct VoxelMap {          // the GPU-resident voxel hash
     int32_t* d_n_vox = nullptr;
 };
 
-struct SortKeyMap {        // packed key <-> compact radix-sort key for one batch
+struct SortKeyMap {        // packed key <-> compact radix-sort key for one batch; entry 0 is the most significant axis
     int32_t mn[3];
     int32_t bits[3];
+    int32_t axis[3];       // which cell coordinate (0 x, 1 y, 2 z) each entry is
+};
+struct SortedCells {       // result of sort_points_by_cell
+    size_t n_valid = 0;
+    uint32_t nseg = 0;
+    SortKeyMap km = {};
+    int passes = 0;
+    const uint64_t* sorted_keys = nullptr;
 };
 
 struct MapBuildCfg {
@@ -60,8 +68,10 @@ struct MapWork {
 // Merges n points (raw records, xyz float32 at offset 0 of each `stride`-byte record, host or device
 // memory) into the map; T (device-independent, row-major R | t) may be null.  Returns the number of
 // radix passes executed through *passes.
-int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, size_t n, size_t stride,
-                     const double* R, const double* t, hipStream_t s, int* passes, std::string& err);
+int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
+                     size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err);
+int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, size_t n, size_t stride, const double* R, const double* t,
+                      DevBuf& ox, DevBuf& oy, DevBuf& oz, size_t* n_out, hipStream_t s, std::string& err);
 int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& keys, std::vector<int32_t>& counts,
                std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
                std::vector<uint8_t>& valid, hipStream_t s, std::string& err);

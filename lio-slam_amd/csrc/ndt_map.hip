@@ -77,7 +77,8 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 // Same-address global atomics from thousands of blocks serialise (~11 ns each), so every block writes one row
 // of partials and a single block folds the rows.
 #define TK_MAX_BLOCKS 1024
-__global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, size_t n, size_t stride, int has_T, const double* Rt,
+// Input is AoS records (raw, stride) or, when stride == 0, three SoA arrays (raw = x, soa_y, soa_z).
+__global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, const double* Rt,
                                                      KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
                                                      int32_t* block_rows) {
     __shared__ int32_t smn[3], smx[3], scnt;
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, s
     __syncthreads();
     int32_t okc = 0, mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float* p = (const float*)(raw + i * stride);
-        float x = p[0], y = p[1], z = p[2];
+        float x, y, z;
+        if (stride) { const float* p = (const float*)(raw + i * stride); x = p[0]; y = p[1]; z = p[2]; }
+        else { x = ((const float*)raw)[i]; y = soa_y[i]; z = soa_z[i]; }
         bool ok = isfinite(x) && isfinite(y) && isfinite(z);
         if (ok && has_T) {   // pcl::transformPointCloud (process.cc:134-136): float64 math, one rounding to float32
             double q[3];
@@ -154,6 +156,8 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
 }
 
 // pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
+// km.mn/bits are listed most-significant axis first; km.axis[] says which cell coordinate each one is
+// (x,y,z for the map build; z,y,x for PCL VoxelGrid's output order).
 __global__ void k_sort_keys(int64_t* keys, size_t n, SortKeyMap km) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -162,16 +166,17 @@ __global__ void k_sort_keys(int64_t* keys, size_t n, SortKeyMap km) {
     if (k != NDT_KEY_EMPTY) {
         int32_t c[3];
         ndt_unpack(k, c[0], c[1], c[2]);
-        sk = ((uint64_t)(c[0] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint64_t)(c[1] - km.mn[1]) << km.bits[2]) |
-             (uint64_t)(c[2] - km.mn[2]);
+        sk = ((uint64_t)(c[km.axis[0]] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint64_t)(c[km.axis[1]] - km.mn[1]) << km.bits[2]) |
+             (uint64_t)(c[km.axis[2]] - km.mn[2]);
     }
     keys[i] = (int64_t)sk;
 }
 __device__ inline int64_t sortkey_to_packed(uint64_t sk, const SortKeyMap& km) {
-    int32_t cz = (int32_t)(sk & ((1ull << km.bits[2]) - 1)) + km.mn[2];
-    int32_t cy = (int32_t)((sk >> km.bits[2]) & ((1ull << km.bits[1]) - 1)) + km.mn[1];
-    int32_t cx = (int32_t)(sk >> (km.bits[1] + km.bits[2])) + km.mn[0];
-    return ndt_pack(cx, cy, cz);
+    int32_t c[3];
+    c[km.axis[2]] = (int32_t)(sk & ((1ull << km.bits[2]) - 1)) + km.mn[2];
+    c[km.axis[1]] = (int32_t)((sk >> km.bits[2]) & ((1ull << km.bits[1]) - 1)) + km.mn[1];
+    c[km.axis[0]] = (int32_t)(sk >> (km.bits[1] + km.bits[2])) + km.mn[0];
+    return ndt_pack(c[0], c[1], c[2]);
 }
 
 // ------------------------------------------------------------------ exclusive scan (uint32)
@@ -473,6 +478,27 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     finalize_slot(sl, ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
 }
 
+// pcl::VoxelGrid centroid (src/slam/src/process.cc:68-73): mean of the cell's points, float64 sum in sorted order,
+// one rounding to float32; output row = segment index (cells in PCL's index order when sorted z,y,x)
+template <int SEG_LANES>
+__global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_start, uint32_t nseg, const float* gx, const float* gy,
+                                                          const float* gz, float* ox, float* oy, float* oz) {
+    uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
+    const int l = threadIdx.x % SEG_LANES;
+    uint32_t s = 0, e = 0;
+    if (g < nseg) { s = seg_start[g]; e = seg_start[g + 1]; }
+    double a[3] = {0, 0, 0};
+    for (uint32_t i = s + l; i < e; i += SEG_LANES) { a[0] += (double)gx[i]; a[1] += (double)gy[i]; a[2] += (double)gz[i]; }
+#pragma unroll
+    for (int o = SEG_LANES / 2; o >= 1; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] += __shfl_xor(a[j], o);
+    if (g < nseg && l == 0) {
+        const double nn = (double)(e - s);
+        ox[g] = (float)(a[0] / nn); oy[g] = (float)(a[1] / nn); oz[g] = (float)(a[2] / nn);
+    }
+}
+
 // ------------------------------------------------------------------ rehash (capacity growth)
 
 __global__ void k_rehash(const VoxSlot* os, const double* om, const double* oc, size_t ocap, VoxSlot* ns, int64_t* nk, double* nm, double* nc, uint64_t nmask) {
@@ -517,19 +543,24 @@ static int map_reserve(VoxelMap& m, size_t want_voxels, hipStream_t s, std::stri
 
 static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; return b; }
 
-int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, size_t n, size_t stride,
-                     const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
-    if (passes) *passes = 0;
-    if (n == 0) return map_reserve(m, 1, s, err);
+// Stage 1 of every cloud ingest: (optional transform,) cell of every point, LSD radix sort of (cell, index),
+// segments (= cells) and the points gathered into sorted order (w.gx/gy/gz).  pts: AoS records in host or device
+// memory, or (stride == 0) three device SoA arrays passed through pts / soa_y / soa_z.
+int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
+                        const double* R, const double* t, bool zyx_order, hipStream_t s, SortedCells* out, std::string& err) {
+    *out = SortedCells();
+    if (n == 0) return NDT_OK;
     if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
-    HIP_TRY(w.raw.ensure(n * stride));
-    HIP_TRY(hipMemcpyAsync(w.raw.p, pts, n * stride, hipMemcpyDefault, s));
+    const unsigned char* d_in = (const unsigned char*)pts;
+    if (stride) {
+        HIP_TRY(w.raw.ensure(n * stride));
+        HIP_TRY(hipMemcpyAsync(w.raw.p, pts, n * stride, hipMemcpyDefault, s));
+        d_in = (const unsigned char*)w.raw.p;
+    }
     HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
     HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.keys_b.ensure(n * 8));
     HIP_TRY(w.vals_a.ensure(n * 4)); HIP_TRY(w.vals_b.ensure(n * 4));
     HIP_TRY(w.misc.ensure(256));
-    int32_t init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
-    HIP_TRY(hipMemcpyAsync(w.misc.p, init, sizeof init, hipMemcpyHostToDevice, s));
     double* dRt = (double*)((char*)w.misc.p + 64);
     if (R) {
         double Rt[12];
@@ -540,7 +571,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     const unsigned nb_tk = std::min<unsigned>(nb256, TK_MAX_BLOCKS);
     HIP_TRY(w.block_rows.ensure((size_t)TK_MAX_BLOCKS * 8 * 4));
-    k_target_keys<<<nb_tk, 256, 0, s>>>((const unsigned char*)w.raw.p, n, stride, R ? 1 : 0, dRt, cfg.kp, w.tx.as<float>(), w.ty.as<float>(),
+    k_target_keys<<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, w.tx.as<float>(), w.ty.as<float>(),
                                         w.tz.as<float>(), w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
     k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>());
     HIP_TRY(hipGetLastError());
@@ -548,13 +579,15 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     HIP_TRY(hipMemcpyAsync(misc, w.misc.p, sizeof misc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const size_t n_valid = (size_t)misc[6];
-    if (n_valid == 0) return map_reserve(m, 1, s, err);
+    if (n_valid == 0) return NDT_OK;
 
     SortKeyMap km;
     int total_bits = 0;
     for (int j = 0; j < 3; ++j) {
-        km.mn[j] = misc[j];
-        km.bits[j] = bits_for((int64_t)misc[3 + j] - misc[j] + 1);
+        const int ax = zyx_order ? 2 - j : j;
+        km.axis[j] = ax;
+        km.mn[j] = misc[ax];
+        km.bits[j] = bits_for((int64_t)misc[3 + ax] - misc[ax] + 1);
         total_bits += km.bits[j];
     }
     k_sort_keys<<<nb256, 256, 0, s>>>(w.keys_a.as<int64_t>(), n, km);
@@ -575,7 +608,6 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         std::swap(ka, kb); std::swap(va, vb);
     }
     HIP_TRY(hipGetLastError());
-    if (passes) *passes = P;
 
     // segments over the valid prefix
     HIP_TRY(w.flags.ensure(n_valid * 4)); HIP_TRY(w.segid.ensure(n_valid * 4));
@@ -588,23 +620,36 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(w.seg_start.ensure(((size_t)nseg + 1) * 4));
     k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-
-    int rc = map_reserve(m, (size_t)m.n_vox + nseg, s, err);
-    if (rc != NDT_OK) return rc;
     HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
     k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
-    if (n_valid / nseg >= 24) {
+    HIP_TRY(hipGetLastError());
+    out->n_valid = n_valid; out->nseg = nseg; out->km = km; out->passes = P; out->sorted_keys = ka;
+    return NDT_OK;
+}
+
+int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
+                     size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
+    if (passes) *passes = 0;
+    SortedCells sc;
+    int rc = sort_points_by_cell(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, s, &sc, err);
+    if (rc != NDT_OK) return rc;
+    if (passes) *passes = sc.passes;
+    if (sc.nseg == 0) return map_reserve(m, 1, s, err);
+    const uint32_t nseg = sc.nseg;
+    rc = map_reserve(m, (size_t)m.n_vox + nseg, s, err);
+    if (rc != NDT_OK) return rc;
+    if (sc.n_valid / nseg >= 24) {
         const unsigned nbs = (unsigned)(((size_t)nseg * 64 + 255) / 256);
-        k_segment_merge<64><<<nbs, 256, 0, s>>>(ka, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), km, cfg,
+        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg,
                                                 m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
     } else {
         const unsigned nbs = (unsigned)(((size_t)nseg * 8 + 255) / 256);
-        k_segment_merge<8><<<nbs, 256, 0, s>>>(ka, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), km, cfg,
+        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg,
                                                m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
     }
     HIP_TRY(hipGetLastError());
     // new voxels = sum of the fresh flags (block sums + one-block spine; no scan-down needed)
+    uint32_t* d_nseg = (uint32_t*)(w.misc.as<int32_t>() + 7);
     {
         const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
         k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(w.flags.as<uint32_t>(), nseg, w.scan_tmp.as<uint32_t>());
@@ -615,6 +660,28 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     HIP_TRY(hipMemcpyAsync(&n_new, d_nseg, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     m.n_vox += n_new;
+    return NDT_OK;
+}
+
+// Scan pre-processing: pcl::transformPointCloud + pcl::VoxelGrid(leaf) of process.cc:62-73 —
+// one centroid per occupied leaf cell, cells in PCL's index order (x fastest, z slowest); xyz only.
+int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, size_t n, size_t stride, const double* R, const double* t,
+                      DevBuf& ox, DevBuf& oy, DevBuf& oz, size_t* n_out, hipStream_t s, std::string& err) {
+    *n_out = 0;
+    SortedCells sc;
+    int rc = sort_points_by_cell(w, leaf_kp, pts, nullptr, nullptr, n, stride, R, t, true, s, &sc, err);
+    if (rc != NDT_OK) return rc;
+    HIP_TRY(ox.ensure((size_t)sc.nseg * 4 + 16)); HIP_TRY(oy.ensure((size_t)sc.nseg * 4 + 16)); HIP_TRY(oz.ensure((size_t)sc.nseg * 4 + 16));
+    if (sc.nseg == 0) return NDT_OK;
+    if (sc.n_valid / sc.nseg >= 24) {
+        k_segment_centroid<64><<<(unsigned)(((size_t)sc.nseg * 64 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.nseg, w.gx.as<float>(),
+                                                                                           w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+    } else {
+        k_segment_centroid<8><<<(unsigned)(((size_t)sc.nseg * 8 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.nseg, w.gx.as<float>(),
+                                                                                         w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+    }
+    HIP_TRY(hipGetLastError());
+    *n_out = sc.nseg;
     return NDT_OK;
 }
 

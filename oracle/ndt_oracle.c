@@ -647,6 +647,57 @@ int ora_export_voxels(ora_handle* h, int64_t* keys, int32_t* counts, double* mea
     return NDT_OK;
 }
 
+/* pcl::transformPointCloud + pcl::VoxelGrid(leaf) of src/slam/src/process.cc:62-73, xyz only: one centroid per occupied
+ * leaf cell (grid rule floor(p_f32 * inv_leaf_f32), as PCL's VoxelGrid), cells ordered by PCL's linear index
+ * (x fastest, z slowest), centroid = float64 mean of the cell's points in input order, rounded once to float32. */
+typedef struct { int32_t c[3]; uint32_t idx; } cell_idx;
+static int cmp_cell_zyx(const void* a, const void* b) {
+    const cell_idx *p = (const cell_idx*)a, *q = (const cell_idx*)b;
+    for (int j = 2; j >= 0; --j) if (p->c[j] != q->c[j]) return p->c[j] < q->c[j] ? -1 : 1;
+    return p->idx < q->idx ? -1 : p->idx > q->idx;
+}
+int ora_voxel_downsample(const void* pts, size_t n, size_t stride, float leaf, const double T[16], float* out, size_t cap, size_t* n_out) {
+    ora_handle hh;
+    memset(&hh, 0, sizeof hh);
+    hh.cfg.key_rule = NDT_KEY_FLOOR_F32;
+    hh.inv_leaf_f32 = 1.0f / leaf; hh.inv_res_d = (double)hh.inv_leaf_f32; hh.res_d = (double)leaf;
+    float* p = (float*)malloc((n ? n : 1) * 12);
+    gather_xyz(pts, n, stride, p);
+    cell_idx* ci = (cell_idx*)malloc((n ? n : 1) * sizeof(cell_idx));
+    double R[3][3], t[3];
+    if (T) mat_from_T(T, R, t);
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float* q = p + 3 * i;
+        if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+        if (T) { double w[3]; xform(R, t, q, w); q[0] = (float)w[0]; q[1] = (float)w[1]; q[2] = (float)w[2]; }
+        if (!target_cell(&hh, q, ci[m].c)) continue;
+        ci[m].idx = (uint32_t)i;
+        ++m;
+    }
+    qsort(ci, m, sizeof(cell_idx), cmp_cell_zyx);
+    size_t no = 0, s = 0;
+    int rc = NDT_OK;
+    while (s < m) {
+        size_t e = s;
+        double a[3] = {0, 0, 0};
+        while (e < m && ci[e].c[0] == ci[s].c[0] && ci[e].c[1] == ci[s].c[1] && ci[e].c[2] == ci[s].c[2]) {
+            const float* q = p + 3 * (size_t)ci[e].idx;
+            a[0] += q[0]; a[1] += q[1]; a[2] += q[2];
+            ++e;
+        }
+        if (out) {
+            if (no >= cap) { rc = NDT_ERR_CAPACITY; break; }
+            for (int j = 0; j < 3; ++j) out[3 * no + j] = (float)(a[j] / (double)(e - s));
+        }
+        ++no;
+        s = e;
+    }
+    if (n_out) *n_out = no;
+    free(ci); free(p);
+    return rc;
+}
+
 int64_t ora_pack_key(int32_t x, int32_t y, int32_t z) { return pack_key(x, y, z); }
 
 /* key of a single map point / of a single transformed source coordinate, for the key-rule vectors */

@@ -67,6 +67,7 @@ def _load():
     lib.ora_num_voxels.argtypes = [vp]
     lib.ora_target_key.argtypes = [vp, vp, vp]
     lib.ora_source_key.argtypes = [vp, vp, vp]
+    lib.ora_voxel_downsample.argtypes = [vp, sz, sz, C.c_float, vp, vp, sz, C.POINTER(sz)]
     lib.ora_pack_key.restype = C.c_int64
     lib.ora_pack_key.argtypes = [C.c_int32] * 3
     return lib
@@ -181,3 +182,15 @@ class Oracle:
         q = np.asarray(q, np.float64); c = np.zeros(3, np.int32)
         ok = lib().ora_source_key(self._h, q.ctypes.data, c.ctypes.data)
         return c if ok else None
+
+
+def voxel_downsample(pts, leaf=0.5, T=None):
+    """pcl::transformPointCloud + pcl::VoxelGrid(leaf) (process.cc:62-73), xyz only, on the CPU."""
+    a, n, s = _pts(pts)
+    t = None if T is None else _T(T)
+    out = np.zeros((max(n, 1), 3), np.float32); no = C.c_size_t()
+    rc = lib().ora_voxel_downsample(a.ctypes.data, n, s, float(leaf), None if t is None else t.ctypes.data,
+                                    out.ctypes.data, n, C.byref(no))
+    if rc:
+        raise RuntimeError(f"ora_voxel_downsample rc={rc}")
+    return out[:no.value].copy()

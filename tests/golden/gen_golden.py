@@ -208,7 +208,30 @@ def gen_pair():
     np.savez_compressed(os.path.join(HERE, "pair.npz"), **out)
 
 
+# ------------------------------------------------------------------ (vi) VoxelGrid centroid downsample (§8(f) N1)
+def gen_downsample():
+    rng = np.random.Generator(np.random.PCG64(13))
+    scene = synth.room_scene(rng)
+    Ts = synth.se3([0.0, 0.0, 0.3], [1.0, 0.5, 0.6])
+    s = synth.scan(scene, "vlp16", Ts, rng)
+    s = s[np.sort(rng.choice(len(s), 6000, replace=False))]
+    s[17] = [np.nan, 1, 1]; s[99] = [0, np.inf, 0]
+    T_il = synth.se3([0.01, -0.02, 0.03], [0.05, 0.0, 0.28])           # a LiDAR -> IMU extrinsic
+    out = {"scan": s, "T": T_il}
+    for leaf in (0.5, 0.3):
+        fin = np.isfinite(s).all(axis=1)
+        p = synth.transform(T_il, s[fin])                                  # float64 math, one rounding to float32
+        cells = np.floor(p * (np.float32(1.0) / np.float32(leaf))).astype(np.int64)   # PCL: float32 multiply, floor
+        order = np.lexsort((np.arange(len(p)), cells[:, 0], cells[:, 1], cells[:, 2]))   # z slowest, x fastest
+        cs = cells[order]
+        bounds = np.flatnonzero(np.any(np.diff(cs, axis=0) != 0, axis=1)) + 1
+        out[f"centroids_{leaf}"] = np.array([p[g].astype(np.float64).mean(0) for g in np.split(order, bounds)])   # float64
+        out[f"cells_{leaf}"] = np.array([cells[g[0]] for g in np.split(order, bounds)], np.int32)
+    np.savez_compressed(os.path.join(HERE, "downsample.npz"), **out)
+
+
 if __name__ == "__main__":
+    gen_downsample()
     gen_keys()
     gen_voxels()
     gen_pair()

@@ -1,0 +1,57 @@
+"""scan pre-processing on the device (process.cc:62-73) and the cloud-free keyframe step
+(process.cc:134-147) against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("leaf", [0.5, 0.3])
+def test_downsample_golden(golden, leaf):
+    import lio_slam_amd as la
+    g = golden["downsample"]
+    n = la.NDT()
+    n.set_source_downsampled(g["scan"], leaf, g["T"])
+    d = n.get_source()
+    ref = g[f"centroids_{leaf}"]
+    assert d.shape == ref.shape
+    assert np.max(np.abs(d.astype(np.float64) - ref)) < 1e-6
+    cells = np.floor(d * (np.float32(1.0) / np.float32(leaf))).astype(np.int32)
+    assert np.array_equal(cells, g[f"cells_{leaf}"])            # every centroid in its own cell, PCL index order
+
+
+def test_frame_loop_without_host_round_trips():
+    """raw scan -> device downsample -> align -> keyframe merge of the resident source, as process.cc:60-153 does."""
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    from oracle.oracle import Oracle, voxel_downsample
+    c = synth.make_config(1, small=True)
+    T_il = synth.se3([0.0, 0.0, 0.01], [0.02, 0.0, 0.1])
+    raw = synth.transform(np.linalg.inv(T_il), c["scan"])       # the scan as the LiDAR saw it
+    n = la.NDT(); o = Oracle()
+    n.set_target(c["map"]); o.set_target(c["map"])
+    n.set_source_downsampled(synth.to_point32(raw), 0.5, T_il)
+    ds = voxel_downsample(raw, 0.5, T_il)
+    gs = n.get_source()
+    assert gs.shape == ds.shape and np.max(np.abs(gs - ds)) < 1e-6
+    exact = float(np.mean(np.all(gs == ds, axis=1)))
+    assert exact > 0.99                                          # same float64 sums up to order; float32 results agree
+    o.set_source(gs)                                             # same source on both sides from here on
+    rg, ro = n.align(c["guess"]), o.align(c["guess"])
+    assert rg["iterations"] == ro["iterations"]
+    dt, dr = pose_error(rg["T"], ro["T"])
+    assert dt < 1e-4 and dr < 1e-5 and rel_err(rg["H"], ro["H"]) < 1e-5
+    n.add_target_from_source(rg["T"]); o.add_target(gs, rg["T"])  # keyframe: the resident source joins the map
+    vg, vo = n.export_voxels(), o.export_voxels()
+    assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"])
+    np.testing.assert_allclose(vg["mean"], vo["mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vg["cov"], vo["cov"], rtol=1e-7, atol=1e-12)
+    eg, eo = n.eval(rg["T"]), o.eval(rg["T"])
+    assert eg["n_effective"] == eo["n_effective"] and rel_err(eg["H"], eo["H"]) < 1e-5
+    # first frame of the reference (process.cc:75-85): the map starts from the first filtered scan
+    m = la.NDT()
+    m.set_source_downsampled(raw, 0.5, T_il)
+    m.add_target_from_source(None)
+    assert m.num_voxels() > 0 and int(m.export_voxels()["counts"].sum()) == m.source_size()

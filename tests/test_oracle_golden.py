@@ -109,3 +109,16 @@ def test_edge_cases():
     assert r["rc"] == -5                                          # too few effective points
     o.set_source(np.zeros((0, 3), np.float32))
     assert o.source_size() == 0
+
+
+@pytest.mark.parametrize("leaf", [0.5, 0.3])
+def test_voxel_downsample(golden, leaf):
+    """§8(f) N1: pcl::transformPointCloud + pcl::VoxelGrid centroids (process.cc:62-73), xyz only."""
+    from oracle.oracle import voxel_downsample
+    g = golden["downsample"]
+    d = voxel_downsample(g["scan"], leaf, g["T"])
+    ref = g[f"centroids_{leaf}"]
+    assert d.shape == ref.shape                                              # same cells, same (PCL index) order
+    assert np.max(np.abs(d.astype(np.float64) - ref)) < 1e-6                 # float32 rounding of a float64 mean
+    assert np.array_equal(np.floor(d * (np.float32(1.0) / np.float32(leaf))).astype(np.int32)[:, 2].argsort(kind="stable"),
+                          np.arange(len(d)))                                 # z is the slowest index
