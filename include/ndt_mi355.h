@@ -158,6 +158,12 @@ int64_t ndt_num_voxels(const ndt_handle* h);
 int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean,
                       double* cov, double* info, uint8_t* valid, size_t cap, size_t* n_out);
 
+/* SURVEY.md §8(f) row N2 — the NDT Hessian as PointCloudFactor's information matrix in place of the constant
+ * diagonal at src/slam/src/process.cc:205-208.  info = scale * H with H symmetrised and its eigenvalues raised to
+ * rel_floor * lambda_max, so that it is positive definite even in a degenerate scene (a corridor leaves H
+ * rank-deficient) and `Eigen::LLT(info)` at src/slam/include/factor.h:224 cannot fail.  Host-only. */
+int ndt_information_from_hessian(const double H[36], double scale, double rel_floor, double info[36]);
+
 /* Packed-key helpers (21 bits per axis, biased by 2^20). */
 int64_t ndt_pack_key(int32_t ix, int32_t iy, int32_t iz);
 void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz);

@@ -86,6 +86,17 @@ class NormalDistributionsTransform {
     bool hasConverged() const { return res_.converged != 0; }
     int getFinalNumIteration() const { return res_.iterations; }
     Matrix6d getHessian() const { Matrix6d m; for (int i = 0; i < 36; ++i) m[i] = res_.H[i]; return m; }
+    // H as a positive-definite information matrix for PointCloudFactor::Create (src/slam/src/process.cc:205-211)
+    Matrix6d getInformation(double scale = 1.0, double rel_floor = 1e-6) const {
+        Matrix6d m{};
+        if (ndt_information_from_hessian(res_.H, scale, rel_floor, m.data()) != NDT_OK) m.fill(0.0);
+        return m;
+    }
+    // Scan pre-processing and keyframe step on the device (process.cc:62-73,87 and 134-147): no host round trip
+    template <class Cloud> void setInputSourceRaw(const Cloud& c, float leaf, const double* T_extrinsic_colmajor = nullptr) {
+        check(ndt_set_source_downsampled(handle(), c.data(), c.size(), sizeof(PointSource), leaf, T_extrinsic_colmajor));
+    }
+    void addSourceToTarget(const double* T_colmajor) { check(ndt_add_target_from_source(handle(), T_colmajor)); }
     const ndt_result& result() const { return res_; }
     int status() const { return status_; }
     std::string lastError() const { return h_ ? ndt_last_error(h_) : "no handle"; }

@@ -23,7 +23,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
-    "ndt_export_voxels", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
+    "ndt_export_voxels", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
@@ -91,6 +91,7 @@ def lib():
     L.ndt_num_voxels.restype = C.c_int64
     L.ndt_num_voxels.argtypes = [vp]
     L.ndt_export_voxels.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.ndt_information_from_hessian.argtypes = [vp, C.c_double, C.c_double, vp]
     L.ndt_pack_key.restype = C.c_int64
     L.ndt_pack_key.argtypes = [C.c_int32] * 3
     L.ndt_unpack_key.argtypes = [C.c_int64, vp, vp, vp]
@@ -315,6 +316,15 @@ class NDT:
         self._chk(lib().ndt_comm_init(self._h, rank, n_ranks, buf))
 
     def comm_destroy(self): self._chk(lib().ndt_comm_destroy(self._h))
+
+
+def information_from_hessian(H, scale=1.0, rel_floor=1e-6):
+    """The NDT Hessian as a positive-definite information matrix for PointCloudFactor (factor.h:220-269)."""
+    Hc = np.ascontiguousarray(H, dtype=np.float64); out = np.zeros((6, 6))
+    rc = lib().ndt_information_from_hessian(Hc.ctypes.data, float(scale), float(rel_floor), out.ctypes.data)
+    if rc:
+        raise NdtError(rc, "ndt_information_from_hessian")
+    return out
 
 
 def unpack_keys(keys):

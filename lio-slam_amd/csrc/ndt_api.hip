@@ -431,6 +431,47 @@ int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mea
     return NDT_OK;
 }
 
+// ---- the NDT Hessian as PointCloudFactor's information (host only, no GPU work)
+
+int ndt_information_from_hessian(const double H[36], double scale, double rel_floor, double info[36]) {
+    if (!H || !info || !(scale > 0.0) || !(rel_floor > 0.0) || rel_floor > 1.0) return NDT_ERR_INVALID_ARG;
+    double A[6][6], V[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double v = 0.5 * (H[i * 6 + j] + H[j * 6 + i]);     // symmetrise
+            if (!isfinite(v)) return NDT_ERR_INVALID_ARG;
+            A[i][j] = v; V[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {                          // cyclic Jacobi
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < 6; ++i) { dia += A[i][i] * A[i][i]; for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j]; }
+        if (off <= 1e-30 * dia || off == 0.0) break;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 6; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - sn * b; A[k][q] = sn * a + c * b; }
+                for (int k = 0; k < 6; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - sn * b; A[q][k] = sn * a + c * b; }
+                for (int k = 0; k < 6; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - sn * b; V[k][q] = sn * a + c * b; }
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < 6; ++i) lmax = fmax(lmax, A[i][i]);
+    if (!(lmax > 0.0)) return NDT_ERR_SINGULAR;
+    const double fl = rel_floor * lmax;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 6; ++k) v += V[i][k] * fmax(A[k][k], fl) * V[j][k];
+            info[i * 6 + j] = scale * v;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = i + 1; j < 6; ++j) info[j * 6 + i] = info[i * 6 + j] = 0.5 * (info[i * 6 + j] + info[j * 6 + i]);
+    return NDT_OK;
+}
+
 int64_t ndt_pack_key(int32_t ix, int32_t iy, int32_t iz) { return ndt_pack(ix, iy, iz); }
 void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz) {
     int32_t a, b, c;

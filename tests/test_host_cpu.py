@@ -104,3 +104,23 @@ def test_sharded_sum_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_information_from_hessian():
+    """§8(f) N2: H -> SPD information for PointCloudFactor (LLT at factor.h:224 must not fail)."""
+    import lio_slam_amd as la
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(6, 6)); H = A @ A.T + 0.1 * np.eye(6)
+    np.testing.assert_allclose(la.information_from_hessian(H, 2.0, 1e-9), 2.0 * H, rtol=1e-10, atol=1e-10)
+    B = rng.normal(size=(6, 3)); Hd = B @ B.T                      # rank 3: a degenerate (corridor-like) scene
+    I = la.information_from_hessian(Hd, 1.0, 1e-4)
+    lam = np.linalg.eigvalsh(I)
+    assert lam.min() > 0 and abs(lam.min() / lam.max() - 1e-4) < 1e-8
+    np.linalg.cholesky(I)                                          # what Eigen::LLT needs
+    assert np.allclose(I, I.T)
+    v = np.linalg.eigh(Hd)[1][:, -1]
+    assert abs(v @ I @ v - v @ Hd @ v) < 1e-8 * abs(v @ Hd @ v)  # well-observed directions are untouched
+    with pytest.raises(la.NdtError):
+        la.information_from_hessian(np.zeros((6, 6)))
+    with pytest.raises(la.NdtError):
+        la.information_from_hessian(np.full((6, 6), np.nan))
