@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -57,6 +58,7 @@ struct ndt_handle {
     GnState* h_state = nullptr;  // pinned
     std::string err;
     int last_radix_passes = 0;
+    int use_links = 1;           // NEARBY7 through the slots' neighbour links (NDT_NO_LINKS=1: seven hashed probes)
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;
@@ -115,6 +117,7 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
     ndt_handle* h = new (std::nothrow) ndt_handle();
     if (!h) return nullptr;
     h->cfg = *cfg;
+    h->use_links = getenv("NDT_NO_LINKS") ? 0 : 1;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
         hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
@@ -302,7 +305,7 @@ static int queue_pass(ndt_handle* h, int do_solve, int force, int64_t* keys_out,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) { e0 = next_event(h); e1 = next_event(h); if (e0) (void)hipEventRecord(e0, h->stream); }
     launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
-                    h->d_state, ep, h->partials.as<double>(), grid, force, keys_out, mask_out, h->stream);
+                    h->d_state, ep, h->partials.as<double>(), grid, force, keys_out, mask_out, h->use_links, h->stream);
     if (h->prof && e1) (void)hipEventRecord(e1, h->stream);
     if (h->comm) {
         // local fixed-order sum into the send row, all-reduce into the receive row, then the same step on
@@ -550,7 +553,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
         for (size_t p0 = 0; p0 < n_pairs; p0 += CH) {
             const int np = (int)std::min(CH, n_pairs - p0);
             launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(), dps, h->map.keys,
-                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, s);
+                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, h->use_links, s);
             launch_reduce_solve_batch(h->bpartials.as<double>() + p0 * (size_t)rows * ACC_N, rows, dst + p0, np, sp, do_solve, force,
                                       h->bdone.as<int32_t>(), s);
         }
@@ -649,7 +652,7 @@ int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_pe
     const EvalParams ep = eval_params(h);
     auto pass = [&]() {
         launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
-                        (uint32_t)(h->map.cap - 1), h->d_state, ep, h->partials.as<double>(), grid, 1, nullptr, nullptr, h->stream);
+                        (uint32_t)(h->map.cap - 1), h->d_state, ep, h->partials.as<double>(), grid, 1, nullptr, nullptr, h->use_links, h->stream);
     };
     for (int i = 0; i < 3; ++i) pass();   // warm
     H_TRY(hipEventRecord(e0, h->stream));
@@ -674,7 +677,7 @@ int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, doub
     auto pass = [&]() {
         launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(),
                               h->b_has_pair_scan ? h->bpair.as<int32_t>() : nullptr, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
-                              h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, 0, (int)h->b_pairs, 1, h->stream);
+                              h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, 0, (int)h->b_pairs, 1, h->use_links, h->stream);
     };
     for (int i = 0; i < 3; ++i) pass();
     H_TRY(hipEventRecord(e0, h->stream));

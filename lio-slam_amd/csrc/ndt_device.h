@@ -2,9 +2,11 @@
 //
 // HBM layout:
 //   source cloud    : three float32 arrays x[], y[], z[] (structure of arrays, coalesced 4-byte lanes)
-//   voxel hash      : open addressing, linear probing, power-of-two capacity, one 64-byte VoxSlot per
-//                     slot — key and the 40 payload bytes the residual kernel needs share one slot, so
-//                     a hit costs one 64-byte segment of one 128-byte line
+//   voxel hash      : open addressing, linear probing, power-of-two capacity; a dense int64 key array (what a
+//                     probe reads) and one 64-byte VoxSlot per slot: the 40 payload bytes the residual
+//                     kernel needs plus the slots of the six face neighbours, so that only the centre
+//                     cell of a point has to be hashed.  Cells that touch a voxel but hold no points are
+//                     kept as "ghost" entries (valid = 0, count = 0) to carry those links.
 //   voxel statistics: per slot, float64 running mean offset (3) and covariance (6) + count, used only
 //                     by map build / incremental merge, never by the residual kernel
 #pragma once
@@ -14,15 +16,13 @@
 #define NDT_KEY_BIAS (1 << 20)
 #define NDT_KEY_EMPTY INT64_MIN
 
+#define NDT_LINK_NONE 0xFFFFFFFFu
 struct __attribute__((aligned(64))) VoxSlot {
-    int64_t key;    // packed voxel key, NDT_KEY_EMPTY when the slot is free
-    int32_t valid;  // 1: n >= min_pts and the regularised inverse is finite
-    float i22;      // info(2,2)
-    float off[3];   // mean - key*res, float32
-    float i00;      // info upper triangle: 00 01 02 11 12 22
-    float i01, i02, i11, i12;
-    int32_t n;      // points merged into this voxel
-    int32_t pad[3];
+    int32_t valid;     // 1: n >= min_pts and the regularised inverse is finite (0 for ghost cells)
+    float i22;         // info(2,2)
+    float off[3];      // mean - key*res, float32
+    float i00, i01, i02, i11, i12;   // info upper triangle: 00 01 02 11 12 (22 above)   -> bytes 0..39 = the 40-byte payload
+    uint32_t link[6];  // slot of the face neighbour -x +x -y +y -z +z, NDT_LINK_NONE if that cell is not in the table
 };
 static_assert(sizeof(VoxSlot) == 64, "VoxSlot must be one 64-byte segment");
 

@@ -28,10 +28,12 @@ struct VoxelMap {          // the GPU-resident voxel hash
     VoxSlot* slots = nullptr;
     int64_t* keys = nullptr;   // [cap+4] dense copy of the slot keys (what a probe reads: 8 B per slot);
                                // keys[cap..cap+3] mirror keys[0..3] so a 32-byte four-key read never wraps
+    int32_t* counts = nullptr; // [cap] points merged into the voxel (0: ghost cell)
     double* mean = nullptr;    // [cap*3] running mean offset from the voxel origin
     double* cov = nullptr;     // [cap*6] running covariance, xx xy xz yy yz zz
     size_t cap = 0;            // power of two (0 = no map)
-    int64_t n_vox = 0;         // host copy of *d_n_vox
+    int64_t n_vox = 0;         // voxels that hold points
+    int64_t n_entries = 0;     // occupied slots: voxels + ghost cells (what the load factor counts)
     int32_t* d_n_vox = nullptr;
 };
 
@@ -59,9 +61,9 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s);
 void map_free(VoxelMap& m);
 hipError_t map_clear(VoxelMap& m, hipStream_t s);
 struct MapWork {
-    DevBuf raw, tx, ty, tz, gx, gy, gz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, segid, seg_start, scan_tmp, misc;
+    DevBuf raw, tx, ty, tz, gx, gy, gz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc;
     void release() {
-        DevBuf* all[] = {&raw, &tx, &ty, &tz, &gx, &gy, &gz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &segid, &seg_start, &scan_tmp, &misc};
+        DevBuf* all[] = {&raw, &tx, &ty, &tz, &gx, &gy, &gz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -81,13 +83,13 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 int residual_grid(size_t n, size_t problems = 1);
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
-                     int64_t* keys_out, uint8_t* mask_out, hipStream_t s);
+                     int64_t* keys_out, uint8_t* mask_out, int linked, hipStream_t s);
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve,
                          int force, hipStream_t s);
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s);
 void launch_solve_only(GnState* st, const double* reduced, const SolveParams& sp, int do_solve, int force, hipStream_t s);
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
                            const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
-                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, hipStream_t s);
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, hipStream_t s);
 void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
                                int do_solve, int force, int32_t* n_done, hipStream_t s);

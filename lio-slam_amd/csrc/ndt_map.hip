@@ -17,26 +17,29 @@
 
 // ------------------------------------------------------------------ table init / alloc
 
-__global__ void k_init_slots(VoxSlot* s, int64_t* keys, size_t cap) {
+__global__ void k_init_slots(VoxSlot* s, int64_t* keys, int32_t* counts, size_t cap) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap + 4) keys[i] = NDT_KEY_EMPTY;
     if (i >= cap) return;
     VoxSlot v = {};
-    v.key = NDT_KEY_EMPTY;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v.link[j] = NDT_LINK_NONE;
     s[i] = v;
+    counts[i] = 0;
 }
 
 hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     hipError_t e;
     if ((e = hipMalloc((void**)&m.slots, cap * sizeof(VoxSlot))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.keys, (cap + 4) * sizeof(int64_t))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&m.counts, cap * sizeof(int32_t))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.mean, cap * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.cov, cap * 6 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.d_n_vox, 256)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(m.d_n_vox, 0, 256, s)) != hipSuccess) return e;
     m.cap = cap;
-    m.n_vox = 0;
-    k_init_slots<<<(unsigned)((cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, cap);
+    m.n_vox = 0; m.n_entries = 0;
+    k_init_slots<<<(unsigned)((cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.counts, cap);
     return hipGetLastError();
 }
 // empties the table in place (keeps the allocation: a rebuild of a same-sized map allocates nothing)
@@ -44,13 +47,14 @@ hipError_t map_clear(VoxelMap& m, hipStream_t s) {
     if (!m.cap) return hipSuccess;
     hipError_t e = hipMemsetAsync(m.d_n_vox, 0, 256, s);
     if (e != hipSuccess) return e;
-    m.n_vox = 0;
-    k_init_slots<<<(unsigned)((m.cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.cap);
+    m.n_vox = 0; m.n_entries = 0;
+    k_init_slots<<<(unsigned)((m.cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.counts, m.cap);
     return hipGetLastError();
 }
 void map_free(VoxelMap& m) {
     if (m.slots) (void)hipFree(m.slots);
     if (m.keys) (void)hipFree(m.keys);
+    if (m.counts) (void)hipFree(m.counts);
     if (m.mean) (void)hipFree(m.mean);
     if (m.cov) (void)hipFree(m.cov);
     if (m.d_n_vox) (void)hipFree(m.d_n_vox);
@@ -382,7 +386,6 @@ __device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3],
     sl->off[0] = (float)mu[0]; sl->off[1] = (float)mu[1]; sl->off[2] = (float)mu[2];
     if (!valid) { info[0] = info[1] = info[2] = info[3] = info[4] = info[5] = 0.f; }
     sl->i00 = info[0]; sl->i01 = info[1]; sl->i02 = info[2]; sl->i11 = info[3]; sl->i12 = info[4]; sl->i22 = info[5];
-    sl->n = n;
     sl->valid = valid;
 }
 
@@ -400,7 +403,8 @@ __global__ void k_gather_sorted(const uint32_t* sv, size_t n, const float* tx, c
 template <int SEG_LANES>
 __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg,
                                                        const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
-                                                       VoxSlot* slots, int64_t* keys, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag) {
+                                                       VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
+                                                       uint32_t* entry_flag) {
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     bool act = g < nseg;
@@ -449,12 +453,12 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     double* mp = mean + slot * 3;
     double* cp = cov + slot * 6;
     int32_t ntot = nb;
-    fresh_flag[g] = fresh ? 1u : 0u;    // summed afterwards: a same-address atomic per new voxel would serialise
-    if (fresh) {
-        sl->key = key;
-        if (slot < 4) keys[mask + 1 + slot] = key;   // mirror entries
-    } else {        // UpdateMeanAndCov (math_utils.h:87-98)
-        double hm = (double)sl->n, cn = (double)nb, tot = hm + cn;
+    const int32_t had = fresh ? 0 : counts[slot];            // 0 also for a ghost cell that now gets its first points
+    entry_flag[g] = fresh ? 1u : 0u;    // new table entry        } summed afterwards: a same-address atomic per voxel
+    fresh_flag[g] = had == 0 ? 1u : 0u; // new voxel with points  } would serialise
+    if (fresh && slot < 4) keys[mask + 1 + slot] = key;      // mirror entries
+    if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
+        double hm = (double)had, cn = (double)nb, tot = hm + cn;
         double nm[3], dh[3], dc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -469,12 +473,13 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
             for (int c = r; c < 3; ++c, ++t) cv[t] = (hm * (cp[t] + dh[r] * dh[c]) + cn * (cv[t] + dc[r] * dc[c])) / tot;
 #pragma unroll
         for (int j = 0; j < 3; ++j) mu[j] = nm[j];
-        ntot = sl->n + nb;
+        ntot = had + nb;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) mp[j] = mu[j];
 #pragma unroll
     for (int j = 0; j < 6; ++j) cp[j] = cv[j];
+    counts[slot] = ntot;
     finalize_slot(sl, ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
 }
 
@@ -501,39 +506,112 @@ __global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_st
 
 // ------------------------------------------------------------------ rehash (capacity growth)
 
-__global__ void k_rehash(const VoxSlot* os, const double* om, const double* oc, size_t ocap, VoxSlot* ns, int64_t* nk, double* nm, double* nc, uint64_t nmask) {
+__global__ void k_rehash(const int64_t* ok, const VoxSlot* os, const int32_t* on, const double* om, const double* oc, size_t ocap,
+                         VoxSlot* ns, int64_t* nk, int32_t* nn, double* nm, double* nc, uint64_t nmask) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ocap) return;
-    VoxSlot v = os[i];
-    if (v.key == NDT_KEY_EMPTY) return;
-    uint64_t slot = ndt_hash_key(v.key) & nmask;
+    const int64_t key = ok[i];
+    if (key == NDT_KEY_EMPTY) return;
+    uint64_t slot = ndt_hash_key(key) & nmask;
     for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&nk[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)v.key);
+        unsigned long long prev = atomicCAS((unsigned long long*)&nk[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
         if ((int64_t)prev == NDT_KEY_EMPTY) break;
         slot = (slot + 1) & nmask;
     }
-    if (slot < 4) nk[nmask + 1 + slot] = v.key;
-    VoxSlot* d = &ns[slot];
-    d->key = v.key;
-    d->valid = v.valid; d->i22 = v.i22; d->off[0] = v.off[0]; d->off[1] = v.off[1]; d->off[2] = v.off[2];
-    d->i00 = v.i00; d->i01 = v.i01; d->i02 = v.i02; d->i11 = v.i11; d->i12 = v.i12; d->n = v.n;
+    if (slot < 4) nk[nmask + 1 + slot] = key;
+    VoxSlot v = os[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v.link[j] = NDT_LINK_NONE;      // slots moved: the links are rebuilt by k_link_all
+    ns[slot] = v;
+    nn[slot] = on[i];
     for (int j = 0; j < 3; ++j) nm[slot * 3 + j] = om[i * 3 + j];
     for (int j = 0; j < 6; ++j) nc[slot * 6 + j] = oc[i * 6 + j];
 }
 
+// ------------------------------------------------------------------ ghost cells and neighbour links
+// A point's residuals come from its own cell and the six face neighbours.  So that only the point's own cell has
+// to be hashed, every cell that touches a voxel is in the table too (a "ghost": no points, valid = 0) and every
+// entry stores the slots of its six neighbours.
+
+__device__ inline uint32_t table_find(const int64_t* keys, uint64_t mask, int64_t key) {
+    uint64_t slot = ndt_hash_key(key) & mask;
+    for (;;) {
+        const int64_t k = keys[slot];
+        if (k == key) return (uint32_t)slot;
+        if (k == NDT_KEY_EMPTY) return NDT_LINK_NONE;
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ inline bool neighbour_key(int64_t key, int d, int64_t* out) {   // d: -x +x -y +y -z +z; false if out of key range
+    int32_t c[3];
+    ndt_unpack(key, c[0], c[1], c[2]);
+    c[d >> 1] += (d & 1) ? 1 : -1;
+    if ((uint32_t)(c[d >> 1] + NDT_KEY_BIAS) >= (uint32_t)(2 * NDT_KEY_BIAS)) return false;
+    *out = ndt_pack(c[0], c[1], c[2]);
+    return true;
+}
+// per batch voxel: how many of its six neighbours are not in the table yet (an upper bound of the ghosts to add)
+__global__ void k_ghost_count(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg, SortKeyMap km, const int64_t* keys,
+                              uint64_t mask, uint32_t* missing) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    const int64_t key = sortkey_to_packed(sk[seg_start[g]], km);
+    uint32_t n = 0;
+    for (int d = 0; d < 6; ++d) {
+        int64_t nk;
+        if (neighbour_key(key, d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++n;
+    }
+    missing[g] = n;
+}
+__global__ void k_ghost_insert(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg, SortKeyMap km, int64_t* keys,
+                               uint64_t mask, uint32_t* inserted) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    const int64_t key = sortkey_to_packed(sk[seg_start[g]], km);
+    uint32_t n = 0;
+    for (int d = 0; d < 6; ++d) {
+        int64_t nk;
+        if (!neighbour_key(key, d, &nk)) continue;
+        uint64_t slot = ndt_hash_key(nk) & mask;
+        for (;;) {
+            unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)nk);
+            if ((int64_t)prev == NDT_KEY_EMPTY) { ++n; if (slot < 4) keys[mask + 1 + slot] = nk; break; }   // slot is zeroed: a ghost
+            if ((int64_t)prev == nk) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    inserted[g] = n;
+}
+__global__ void k_link_all(const int64_t* keys, VoxSlot* slots, size_t cap) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const int64_t key = keys[i];
+    if (key == NDT_KEY_EMPTY) return;
+    uint32_t l[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        int64_t nk;
+        l[d] = neighbour_key(key, d, &nk) ? table_find(keys, cap - 1, nk) : NDT_LINK_NONE;
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) slots[i].link[d] = l[d];
+}
+
 static size_t pow2_at_least(size_t v) { size_t c = 1024; while (c < v) c <<= 1; return c; }
 
-static int map_reserve(VoxelMap& m, size_t want_voxels, hipStream_t s, std::string& err) {
-    size_t need = pow2_at_least(want_voxels * 2);       // load factor <= 1/2
-    if (m.cap >= need && !(m.n_vox == 0 && m.cap > 16 * need)) return NDT_OK;   // an empty, far too large table is re-made
-    if (m.n_vox == 0 && m.cap) { HIP_TRY(hipStreamSynchronize(s)); map_free(m); }
-    size_t ncap = pow2_at_least(want_voxels * 4);        // grow with headroom
+// want_entries counts occupied slots (voxels + ghost cells)
+static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::string& err) {
+    size_t need = pow2_at_least(want_entries * 2);       // load factor <= 1/2
+    if (m.cap >= need && !(m.n_entries == 0 && m.cap > 16 * need)) return NDT_OK;   // an empty, far too large table is re-made
+    if (m.n_entries == 0 && m.cap) { HIP_TRY(hipStreamSynchronize(s)); map_free(m); }
+    size_t ncap = pow2_at_least(want_entries * 4);        // grow with headroom
     VoxelMap nm;
     HIP_TRY(map_alloc(nm, ncap, s));
     if (m.cap) {
-        k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.mean, nm.cov, ncap - 1);
+        k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.counts, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.counts, nm.mean,
+                                                                nm.cov, ncap - 1);
         HIP_TRY(hipGetLastError());
-        nm.n_vox = m.n_vox;
+        nm.n_vox = m.n_vox; nm.n_entries = m.n_entries;
         HIP_TRY(hipStreamSynchronize(s));
         map_free(m);
     }
@@ -636,30 +714,51 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     if (passes) *passes = sc.passes;
     if (sc.nseg == 0) return map_reserve(m, 1, s, err);
     const uint32_t nseg = sc.nseg;
-    rc = map_reserve(m, (size_t)m.n_vox + nseg, s, err);
+    rc = map_reserve(m, (size_t)m.n_entries + nseg, s, err);
     if (rc != NDT_OK) return rc;
+    HIP_TRY(w.flags2.ensure((size_t)nseg * 4 + 16));
+    const uint32_t* segs = w.seg_start.as<uint32_t>();
     if (sc.n_valid / nseg >= 24) {
         const unsigned nbs = (unsigned)(((size_t)nseg * 64 + 255) / 256);
-        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg,
-                                                m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.slots, m.keys,
+                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>());
     } else {
         const unsigned nbs = (unsigned)(((size_t)nseg * 8 + 255) / 256);
-        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, w.seg_start.as<uint32_t>(), nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg,
-                                               m.slots, m.keys, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.slots, m.keys,
+                                               m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>());
     }
     HIP_TRY(hipGetLastError());
-    // new voxels = sum of the fresh flags (block sums + one-block spine; no scan-down needed)
-    uint32_t* d_nseg = (uint32_t*)(w.misc.as<int32_t>() + 7);
-    {
-        const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
-        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(w.flags.as<uint32_t>(), nseg, w.scan_tmp.as<uint32_t>());
-        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, d_nseg);
-    }
+    // sums of per-voxel flags (block sums + one-block spine; no scan-down needed): misc[8..11]
+    uint32_t* d_sums = (uint32_t*)(w.misc.as<int32_t>() + 8);
+    const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
+    const unsigned nbseg = (unsigned)((nseg + 255) / 256);
+    auto sum_flags = [&](const uint32_t* f, uint32_t* out) {
+        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(f, nseg, w.scan_tmp.as<uint32_t>());
+        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, out);
+    };
+    sum_flags(w.flags.as<uint32_t>(), d_sums + 0);      // new voxels
+    sum_flags(w.flags2.as<uint32_t>(), d_sums + 1);     // new table entries
+    k_ghost_count<<<nbseg, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+    sum_flags(w.flags.as<uint32_t>(), d_sums + 2);      // neighbours not in the table yet (upper bound)
     HIP_TRY(hipGetLastError());
-    uint32_t n_new = 0;
-    HIP_TRY(hipMemcpyAsync(&n_new, d_nseg, 4, hipMemcpyDeviceToHost, s));
+    uint32_t sums[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(sums, d_sums, 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    m.n_vox += n_new;
+    m.n_vox += sums[0];
+    m.n_entries += sums[1];
+    if (sums[2]) {
+        rc = map_reserve(m, (size_t)m.n_entries + sums[2], s, err);
+        if (rc != NDT_OK) return rc;
+        k_ghost_insert<<<nbseg, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+        sum_flags(w.flags.as<uint32_t>(), d_sums + 3);
+    }
+    k_link_all<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.cap);
+    HIP_TRY(hipGetLastError());
+    if (sums[2]) {
+        HIP_TRY(hipMemcpyAsync(sums + 3, d_sums + 3, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m.n_entries += sums[3];
+    }
     return NDT_OK;
 }
 
@@ -687,14 +786,14 @@ int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, siz
 
 // ------------------------------------------------------------------ export (parity checks)
 
-__global__ void k_export(const VoxSlot* slots, const double* mean, const double* cov, size_t cap, uint32_t* counter, VoxSlot* oslots,
-                         double* omean, double* ocov) {
+__global__ void k_export(const int64_t* keys, const VoxSlot* slots, const int32_t* counts, const double* mean, const double* cov, size_t cap,
+                         uint32_t* counter, int64_t* okeys, int32_t* ocounts, VoxSlot* oslots, double* omean, double* ocov) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
-    VoxSlot v = slots[i];
-    if (v.key == NDT_KEY_EMPTY) return;
+    if (keys[i] == NDT_KEY_EMPTY || counts[i] == 0) return;     // free slot or ghost cell
     uint32_t o = atomicAdd(counter, 1u);
-    oslots[o] = v;
+    okeys[o] = keys[i]; ocounts[o] = counts[i];
+    oslots[o] = slots[i];
     for (int j = 0; j < 3; ++j) omean[(size_t)o * 3 + j] = mean[i * 3 + j];
     for (int j = 0; j < 6; ++j) ocov[(size_t)o * 6 + j] = cov[i * 6 + j];
 }
@@ -705,28 +804,34 @@ int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& key
     const size_t nv = (size_t)m.n_vox;
     keys.assign(nv, 0); counts.assign(nv, 0); mean.assign(nv * 3, 0); cov.assign(nv * 9, 0); info.assign(nv * 9, 0); valid.assign(nv, 0);
     if (!nv) return NDT_OK;
-    DevBuf dcnt, dsl, dm, dc;
+    DevBuf dcnt, dsl, dm, dc, dk, dn;
     HIP_TRY(dcnt.ensure(4)); HIP_TRY(dsl.ensure(nv * sizeof(VoxSlot))); HIP_TRY(dm.ensure(nv * 24)); HIP_TRY(dc.ensure(nv * 48));
+    HIP_TRY(dk.ensure(nv * 8)); HIP_TRY(dn.ensure(nv * 4));
     HIP_TRY(hipMemsetAsync(dcnt.p, 0, 4, s));
-    k_export<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.slots, m.mean, m.cov, m.cap, dcnt.as<uint32_t>(), dsl.as<VoxSlot>(), dm.as<double>(), dc.as<double>());
+    k_export<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.counts, m.mean, m.cov, m.cap, dcnt.as<uint32_t>(), dk.as<int64_t>(),
+                                                             dn.as<int32_t>(), dsl.as<VoxSlot>(), dm.as<double>(), dc.as<double>());
     HIP_TRY(hipGetLastError());
     std::vector<VoxSlot> hs(nv);
+    std::vector<int64_t> hk(nv);
+    std::vector<int32_t> hn(nv);
     std::vector<double> hm(nv * 3), hc(nv * 6);
+    HIP_TRY(hipMemcpyAsync(hk.data(), dk.p, nv * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hn.data(), dn.p, nv * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hs.data(), dsl.p, nv * sizeof(VoxSlot), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hm.data(), dm.p, nv * 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hc.data(), dc.p, nv * 48, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    dcnt.release(); dsl.release(); dm.release(); dc.release();
+    dcnt.release(); dsl.release(); dm.release(); dc.release(); dk.release(); dn.release();
     std::vector<size_t> ord(nv);
     std::iota(ord.begin(), ord.end(), 0);
-    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return hs[a].key < hs[b].key; });
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
     static const int U[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     for (size_t o = 0; o < nv; ++o) {
         const size_t i = ord[o];
         const VoxSlot& v = hs[i];
         int32_t c[3];
-        ndt_unpack(v.key, c[0], c[1], c[2]);
-        keys[o] = v.key; counts[o] = v.n; valid[o] = (uint8_t)v.valid;
+        ndt_unpack(hk[i], c[0], c[1], c[2]);
+        keys[o] = hk[i]; counts[o] = hn[i]; valid[o] = (uint8_t)v.valid;
         const double inf6[6] = {v.i00, v.i01, v.i02, v.i11, v.i12, v.i22};
         for (int r = 0; r < 3; ++r) {
             mean[o * 3 + r] = (double)c[r] * kp.res_d + hm[i * 3 + r];

@@ -27,6 +27,91 @@ struct __attribute__((aligned(8))) Key2 { int64_t x, y; };   // two adjacent ent
 
 __device__ inline bool cell_ok(int32_t v) { return (uint32_t)(v + NDT_KEY_BIAS) < (uint32_t)(2 * NDT_KEY_BIAS); }
 
+// the 40 payload bytes of a slot: {valid, i22, off.x, off.y} {off.z, i00, i01, i02} {i11, i12}
+struct Payload { int4 a; float4 b; float2 c; };
+__device__ __forceinline__ Payload load_payload(const VoxSlot* __restrict__ slots, uint32_t slot) {
+    const int4* sp = (const int4*)(slots + (slot != SLOT_NONE ? slot : 0u));   // slot 0 stands in for a miss: no predicated load
+    Payload p;
+    p.a = sp[0];
+    p.b = *(const float4*)(sp + 1);
+    p.c = *(const float2*)(sp + 2);
+    return p;
+}
+
+// Mahalanobis residual of the point against the K voxels in pay[], chi^2 gate, select-free accumulation of
+// S = sum Sigma^-1, g = sum Sigma^-1 e, chi2, n_eff, hits.  Same operation order as the oracle.
+template <int K>
+__device__ __forceinline__ unsigned gate_and_sum(const Payload* pay, const uint32_t* fs, const double* q, const int32_t* c,
+                                                 const EvalParams& ep, double* S, double* g, double* acc) {
+    unsigned hitmask = 0;
+#pragma unroll
+    for (int pr = 0; pr < K; ++pr) {
+        const int dx = pr == 1 ? -1 : pr == 2 ? 1 : 0, dy = pr == 3 ? -1 : pr == 4 ? 1 : 0, dz = pr == 5 ? -1 : pr == 6 ? 1 : 0;
+        const bool vox = fs[pr] != SLOT_NONE && pay[pr].a.x != 0;      // a valid voxel was found
+        const double i22 = __int_as_float(pay[pr].a.y), i00 = pay[pr].b.y, i01 = pay[pr].b.z, i02 = pay[pr].b.w, i11 = pay[pr].c.x,
+                     i12 = pay[pr].c.y;
+        const double e0 = (q[0] - (double)(c[0] + dx) * ep.kp.res_d) - (double)__int_as_float(pay[pr].a.z);
+        const double e1 = (q[1] - (double)(c[1] + dy) * ep.kp.res_d) - (double)__int_as_float(pay[pr].a.w);
+        const double e2 = (q[2] - (double)(c[2] + dz) * ep.kp.res_d) - (double)pay[pr].b.x;
+        const double g0 = (i00 * e0 + i01 * e1) + i02 * e2;
+        const double g1 = (i01 * e0 + i11 * e1) + i12 * e2;
+        const double g2 = (i02 * e0 + i12 * e1) + i22 * e2;
+        const double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
+        const bool ok = vox && chi2 <= ep.outlier_th;               // false for NaN
+        hitmask |= ok ? 1u << pr : 0u;
+        // w is exactly 0 or 1 and every operand is finite (payloads of valid voxels are finite, slot 0 stands in for
+        // misses), so fma(w, v, s) equals the plain s + v when the residual is accepted and s otherwise
+        const double w = ok ? 1.0 : 0.0;
+        acc[ACC_HITS] += vox ? 1.0 : 0.0;
+        S[0] = fma(w, i00, S[0]); S[1] = fma(w, i01, S[1]); S[2] = fma(w, i02, S[2]);
+        S[3] = fma(w, i11, S[3]); S[4] = fma(w, i12, S[4]); S[5] = fma(w, i22, S[5]);
+        g[0] = fma(w, g0, g[0]); g[1] = fma(w, g1, g[1]); g[2] = fma(w, g2, g[2]);
+        acc[ACC_CHI2] = fma(w, chi2, acc[ACC_CHI2]);
+        acc[ACC_NEFF] += w;
+    }
+    return hitmask;
+}
+
+// Folds one point's S and g through J = [-R hat(q) | I] into the 21 + 6 accumulators.
+__device__ __forceinline__ void fold_point(const Pose& P, float xf, float yf, float zf, unsigned hitmask, const double* S, const double* g,
+                                           double* acc) {
+    if (!__any(hitmask != 0)) return;
+    // A = -R hat(q):  H = [A^T S A, A^T S; S A, S],  b = [-A^T g; -g]
+    const double x = xf, y = yf, z = zf;
+    const double* R = P.R;
+    // (explicit fma from here on: this part is compared at the 1e-5 tolerance, not bit for bit)
+    double A[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        A[r][0] = fma(R[3 * r + 2], y, -(R[3 * r + 1] * z));
+        A[r][1] = fma(R[3 * r + 0], z, -(R[3 * r + 2] * x));
+        A[r][2] = fma(R[3 * r + 1], x, -(R[3 * r + 0] * y));
+    }
+    const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+    double SA[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) SA[r][cc] = fma(Sm[r][2], A[2][cc], fma(Sm[r][1], A[1][cc], Sm[r][0] * A[0][cc]));
+    // upper triangle of the 6x6, row-major: rows 0..2 = [A^T S A](r, r..2) then [A^T S](r, 0..2); rows 3..5 = S
+    int tix = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = r; cc < 3; ++cc) { acc[tix] = fma(A[0][r], SA[0][cc], fma(A[1][r], SA[1][cc], fma(A[2][r], SA[2][cc], acc[tix]))); ++tix; }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) acc[tix++] += SA[cc][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = r; cc < 3; ++cc) acc[tix++] += Sm[r][cc];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[21 + r] = fma(-A[0][r], g[0], fma(-A[1][r], g[1], fma(-A[2][r], g[2], acc[21 + r])));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[24 + r] -= g[r];
+}
+
 // Accumulates one source point into acc[0..29].  Returns the hit mask; *cell_key gets the centre key (or EMPTY).
 template <int K>
 __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
@@ -89,81 +174,67 @@ __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float y
         }
     }
     // ---- round 2: payload of every matched slot (slot 0 stands in for a miss), all in flight together
-    int4 hd[K];
-    float4 p1[K], p2[K];
+    Payload pay[K];
 #pragma unroll
-    for (int pr = 0; pr < K; ++pr) {
-        const int4* sp = (const int4*)(slots + (fs[pr] != SLOT_NONE ? fs[pr] : 0u));
-        hd[pr] = sp[0];                        // key, valid, i22
-        p1[pr] = *(const float4*)(sp + 1);     // off.xyz, i00
-        p2[pr] = *(const float4*)(sp + 2);     // i01 i02 i11 i12
-    }
+    for (int pr = 0; pr < K; ++pr) pay[pr] = load_payload(slots, fs[pr]);
     double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    unsigned hitmask = 0;
-#pragma unroll
-    for (int pr = 0; pr < K; ++pr) {
-        const int dx = pr == 1 ? -1 : pr == 2 ? 1 : 0, dy = pr == 3 ? -1 : pr == 4 ? 1 : 0, dz = pr == 5 ? -1 : pr == 6 ? 1 : 0;
-        const bool vox = fs[pr] != SLOT_NONE && hd[pr].z != 0;      // a valid voxel was found
-        const double i00 = p1[pr].w, i01 = p2[pr].x, i02 = p2[pr].y, i11 = p2[pr].z, i12 = p2[pr].w, i22 = __int_as_float(hd[pr].w);
-        const double e0 = (q[0] - (double)(c[0] + dx) * ep.kp.res_d) - (double)p1[pr].x;
-        const double e1 = (q[1] - (double)(c[1] + dy) * ep.kp.res_d) - (double)p1[pr].y;
-        const double e2 = (q[2] - (double)(c[2] + dz) * ep.kp.res_d) - (double)p1[pr].z;
-        const double g0 = (i00 * e0 + i01 * e1) + i02 * e2;
-        const double g1 = (i01 * e0 + i11 * e1) + i12 * e2;
-        const double g2 = (i02 * e0 + i12 * e1) + i22 * e2;
-        const double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
-        const bool ok = vox && chi2 <= ep.outlier_th;               // false for NaN
-        hitmask |= ok ? 1u << pr : 0u;
-        // w is exactly 0 or 1 and every operand is finite (payloads of valid voxels are finite, slot 0 stands in for
-        // misses), so fma(w, v, s) equals the plain s + v when the residual is accepted and s otherwise
-        const double w = ok ? 1.0 : 0.0;
-        acc[ACC_HITS] += vox ? 1.0 : 0.0;
-        S[0] = fma(w, i00, S[0]); S[1] = fma(w, i01, S[1]); S[2] = fma(w, i02, S[2]);
-        S[3] = fma(w, i11, S[3]); S[4] = fma(w, i12, S[4]); S[5] = fma(w, i22, S[5]);
-        g[0] = fma(w, g0, g[0]); g[1] = fma(w, g1, g[1]); g[2] = fma(w, g2, g[2]);
-        acc[ACC_CHI2] = fma(w, chi2, acc[ACC_CHI2]);
-        acc[ACC_NEFF] += w;
-    }
-    if (!__any(hitmask != 0)) return 0;
-    // A = -R hat(q):  H = [A^T S A, A^T S; S A, S],  b = [-A^T g; -g]
-    const double x = xf, y = yf, z = zf;
-    const double* R = P.R;
-    // (explicit fma from here on: this part is compared at the 1e-5 tolerance, not bit for bit)
-    double A[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        A[r][0] = fma(R[3 * r + 2], y, -(R[3 * r + 1] * z));
-        A[r][1] = fma(R[3 * r + 0], z, -(R[3 * r + 2] * x));
-        A[r][2] = fma(R[3 * r + 1], x, -(R[3 * r + 0] * y));
-    }
-    const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
-    double SA[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) SA[r][cc] = fma(Sm[r][2], A[2][cc], fma(Sm[r][1], A[1][cc], Sm[r][0] * A[0][cc]));
-    // upper triangle of the 6x6, row-major: rows 0..2 = [A^T S A](r, r..2) then [A^T S](r, 0..2); rows 3..5 = S
-    int tix = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int cc = r; cc < 3; ++cc) { acc[tix] = fma(A[0][r], SA[0][cc], fma(A[1][r], SA[1][cc], fma(A[2][r], SA[2][cc], acc[tix]))); ++tix; }
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) acc[tix++] += SA[cc][r];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = r; cc < 3; ++cc) acc[tix++] += Sm[r][cc];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[21 + r] = fma(-A[0][r], g[0], fma(-A[1][r], g[1], fma(-A[2][r], g[2], acc[21 + r])));
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[24 + r] -= g[r];
+    const unsigned hitmask = gate_and_sum<K>(pay, fs, q, c, ep, S, g, acc);
+    fold_point(P, xf, yf, zf, hitmask, S, g, acc);
     return hitmask;
 }
 
 // Butterfly reduce-scatter of 32 per-lane doubles over the 64 lanes of a wave: after it, lanes 2i and 2i+1
 // both hold the wave total of acc[i].  32 exchanges; the summation tree is fixed.
+// NEARBY7 through the neighbour links: only the point's own cell is hashed; its slot holds the slots of the six
+// face neighbours (ghost cells make sure a cell next to a voxel is always in the table).  Same probe order and the
+// same arithmetic as point_terms<7>, so both give identical bits.
+__device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
+                                                       const VoxSlot* __restrict__ slots, uint32_t mask, const EvalParams& ep,
+                                                       double* acc, int64_t* cell_key) {
+    double q[3];
+    ndt_xform(P.R, P.t, xf, yf, zf, q);
+    int32_t c[3];
+    if (!ndt_source_cell(ep.kp, q, c)) { *cell_key = NDT_KEY_EMPTY; return 0; }
+    const int64_t ckey = ndt_pack(c[0], c[1], c[2]);
+    *cell_key = ckey;
+    const uint32_t s0 = ndt_hash_cell(c[0], c[1], c[2]) & mask;
+    const Key2* kp = (const Key2*)(keys + s0);
+    const Key2 ka = kp[0], kb = kp[1];
+    const bool m0 = ka.x == ckey, m1 = ka.y == ckey, m2 = kb.x == ckey, m3 = kb.y == ckey;
+    const bool e0 = ka.x == NDT_KEY_EMPTY, e1 = ka.y == NDT_KEY_EMPTY, e2 = kb.x == NDT_KEY_EMPTY, e3 = kb.y == NDT_KEY_EMPTY;
+    const uint32_t off = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
+    const bool found = m0 || (!e0 && (m1 || (!e1 && (m2 || (!e2 && m3)))));
+    uint32_t fs0 = found ? (s0 + off) & mask : SLOT_NONE;
+    bool pending = !(m0 || e0 || m1 || e1 || m2 || e2 || m3 || e3);
+    uint32_t cur = (s0 + 4) & mask;
+    while (__any(pending)) {          // chains longer than four slots (rare)
+        const int64_t k = keys[cur];
+        const bool hit = pending && k == ckey, stop = pending && (hit || k == NDT_KEY_EMPTY);
+        fs0 = hit ? cur : fs0;
+        pending = pending && !stop;
+        cur = pending ? (cur + 1) & mask : cur;
+    }
+    // centre slot: payload and the six links in one 64-byte read
+    const int4* sp = (const int4*)(slots + (fs0 != SLOT_NONE ? fs0 : 0u));
+    const int4 a = sp[0];
+    const float4 b = *(const float4*)(sp + 1);
+    const int4 c2 = sp[2], d = sp[3];
+    const bool have = fs0 != SLOT_NONE;
+    uint32_t fs[7];
+    fs[0] = fs0;
+    fs[1] = have ? (uint32_t)c2.z : SLOT_NONE; fs[2] = have ? (uint32_t)c2.w : SLOT_NONE;
+    fs[3] = have ? (uint32_t)d.x : SLOT_NONE;  fs[4] = have ? (uint32_t)d.y : SLOT_NONE;
+    fs[5] = have ? (uint32_t)d.z : SLOT_NONE;  fs[6] = have ? (uint32_t)d.w : SLOT_NONE;
+    Payload pay[7];
+    pay[0].a = a; pay[0].b = b; pay[0].c = make_float2(__int_as_float(c2.x), __int_as_float(c2.y));
+#pragma unroll
+    for (int pr = 1; pr < 7; ++pr) pay[pr] = load_payload(slots, fs[pr]);
+    double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    const unsigned hitmask = gate_and_sum<7>(pay, fs, q, c, ep, S, g, acc);
+    fold_point(P, xf, yf, zf, hitmask, S, g, acc);
+    return hitmask;
+}
+
 // Butterfly reduce-scatter of 32 per-lane doubles over the 64 lanes of a wave: after it, lanes 2i and 2i+1 both
 // hold the wave total of acc[i].  31 exchanges in a fixed tree.  The two widest levels use the gfx950 row-swap
 // instructions (v_permlane32_swap / v_permlane16_swap: no select, no LDS crossbar); the rest are lane shuffles.
@@ -217,7 +288,7 @@ __device__ __forceinline__ void block_store_row(double* acc, double* __restrict_
     }
 }
 
-template <int K, bool CELLS>
+template <int K, bool CELLS, bool LINKED>
 __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
                                                           const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
                                                           const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st,
@@ -238,7 +309,8 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
     while (i < n) {
         int64_t ck;
-        const unsigned hm = point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        const unsigned hm = LINKED ? point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck)
+                                   : point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         if (CELLS) { keys_out[i] = ck; mask_out[i] = (uint8_t)hm; }
         i += gridDim.x * RES1_THREADS;
         if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
@@ -248,7 +320,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
 
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
 // pair's scan.  Scans are stored back to back in xs/ys/zs; pair p reads scan pair_scan[p] (or p) and its own GnState.
-template <int K>
+template <int K, bool LINKED>
 __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __restrict__ xs, const float* __restrict__ ys,
                                                                 const float* __restrict__ zs, const int64_t* __restrict__ scan_off,
                                                                 const int32_t* __restrict__ pair_scan, const int64_t* __restrict__ keys,
@@ -273,7 +345,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
     while (i < hi) {
         int64_t ck;
-        point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        if (LINKED) point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        else point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         i += (int64_t)gridDim.x * RES_THREADS;
         if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     }
@@ -300,10 +373,12 @@ int residual_grid(size_t n, size_t problems) {
 
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
-                     int64_t* keys_out, uint8_t* mask_out, hipStream_t s) {
-#define LAUNCH(KK, CC) k_residual<KK, CC><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st, ep, partials, force, keys_out, mask_out)
-    if (ep.nearby == 7) { if (keys_out) LAUNCH(7, true); else LAUNCH(7, false); }
-    else { if (keys_out) LAUNCH(1, true); else LAUNCH(1, false); }
+                     int64_t* keys_out, uint8_t* mask_out, int linked, hipStream_t s) {
+#define LAUNCH(KK, CC, LL) k_residual<KK, CC, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st, ep, partials, force, keys_out, mask_out)
+    if (ep.nearby == 7) {
+        if (linked) { if (keys_out) LAUNCH(7, true, true); else LAUNCH(7, false, true); }
+        else { if (keys_out) LAUNCH(7, true, false); else LAUNCH(7, false, false); }
+    } else { if (keys_out) LAUNCH(1, true, false); else LAUNCH(1, false, false); }
 #undef LAUNCH
 }
 
@@ -471,14 +546,15 @@ __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const doubl
 
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
                            const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
-                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, hipStream_t s) {
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, hipStream_t s) {
     dim3 grid((unsigned)rows_per_pair, (unsigned)n_pairs);
     const int32_t* ps = pair_scan ? pair_scan + pair0 : nullptr;
     // without pair_scan pair p reads scan p, so the offsets are shifted together with the states
     const int64_t* so = pair_scan ? scan_off : scan_off + pair0;
     double* pp = partials + (size_t)pair0 * rows_per_pair * ACC_N;
-    if (ep.nearby == 7) k_residual_batch<7><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
-    else k_residual_batch<1><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    if (ep.nearby == 7 && linked) k_residual_batch<7, true><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    else if (ep.nearby == 7) k_residual_batch<7, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    else k_residual_batch<1, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
 }
 void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
                                int do_solve, int force, int32_t* n_done, hipStream_t s) {

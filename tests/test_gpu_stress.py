@@ -76,3 +76,22 @@ def test_ragged_inputs_device_pointers_and_strides():
         n.set_source((0, 10, 12))                                # null buffer
     with pytest.raises(la.NdtError):
         n.set_target((1, 10, 10))                                # stride not a multiple of 4 / below 12
+
+
+def test_linked_and_hashed_nearby7_agree_bit_for_bit(monkeypatch):
+    """NEARBY7 through the slots' neighbour links (default) and through seven hashed probes give identical bits."""
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    c = synth.make_config(1, small=True)
+    res = []
+    for no_links in (False, True):
+        if no_links:
+            monkeypatch.setenv("NDT_NO_LINKS", "1")
+        n = la.NDT()
+        n.set_target(c["map"][: len(c["map"]) // 2]); n.add_target(c["map"][len(c["map"]) // 2:])   # links rebuilt after a merge
+        n.set_source(c["scan"])
+        res.append((n.source_cells(c["guess"]), n.eval(c["guess"]), n.align(c["guess"])))
+    (ka, ma), ea, ra = res[0]; (kb, mb), eb, rb = res[1]
+    assert np.array_equal(ka, kb) and np.array_equal(ma, mb)
+    assert np.array_equal(ea["H"], eb["H"]) and np.array_equal(ea["b"], eb["b"]) and ea["n_effective"] == eb["n_effective"]
+    assert np.array_equal(ra["T"], rb["T"]) and ra["iterations"] == rb["iterations"]
