@@ -183,8 +183,6 @@ __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float y
     return hitmask;
 }
 
-// Butterfly reduce-scatter of 32 per-lane doubles over the 64 lanes of a wave: after it, lanes 2i and 2i+1
-// both hold the wave total of acc[i].  32 exchanges; the summation tree is fixed.
 // NEARBY7 through the neighbour links: only the point's own cell is hashed; its slot holds the slots of the six
 // face neighbours (ghost cells make sure a cell next to a voxel is always in the table).  Same probe order and the
 // same arithmetic as point_terms<7>, so both give identical bits.
