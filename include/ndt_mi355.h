@@ -158,6 +158,20 @@ int64_t ndt_num_voxels(const ndt_handle* h);
 int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean,
                       double* cov, double* info, uint8_t* valid, size_t cap, size_t* n_out);
 
+/* SURVEY.md §8(f) row N3 (map serialisation) — the reference keeps pc_key_ only in RAM and rebuilds the voxel grid from
+ * it (src/slam/src/process.cc:78,147); a resident map that was grown by incremental merges has no such cloud to
+ * rebuild from, so it can be saved and restored.  The blob is position-independent, little-endian:
+ *   bytes 0-7 "NDTMI355", u32 version (1), f32 resolution, i32 key_rule, i32 reserved, u64 n_voxels, 32 reserved bytes
+ *   (64-byte header), then int64 keys[n] (ascending), float64 mean_offset[n][3] (relative to key*resolution),
+ *   float64 cov[n][6] (upper triangle), int32 counts[n].
+ * ndt_map_save: *n_bytes = size needed; writes only when buf != NULL and cap_bytes is large enough (else
+ * NDT_ERR_CAPACITY when buf != NULL).  ndt_map_load replaces the resident map; the blob's resolution and key_rule
+ * must equal the handle's; validity and the float32 payload are derived again under the handle's current
+ * min_pts_in_voxel / eig_floor_ratio, so a map loaded under the configuration it was saved with answers bit for bit
+ * like the original and later ndt_add_target calls continue from the same statistics. */
+int ndt_map_save(ndt_handle* h, void* buf, size_t cap_bytes, size_t* n_bytes);
+int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes);
+
 /* SURVEY.md §8(f) row N2 — the NDT Hessian as PointCloudFactor's information matrix in place of the constant
  * diagonal at src/slam/src/process.cc:205-208.  info = scale * H with H symmetrised and its eigenvalues raised to
  * rel_floor * lambda_max, so that it is positive definite even in a degenerate scene (a corridor leaves H

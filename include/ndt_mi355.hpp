@@ -97,6 +97,15 @@ class NormalDistributionsTransform {
         check(ndt_set_source_downsampled(handle(), c.data(), c.size(), sizeof(PointSource), leaf, T_extrinsic_colmajor));
     }
     void addSourceToTarget(const double* T_colmajor) { check(ndt_add_target_from_source(handle(), T_colmajor)); }
+    // Voxel-map serialisation (ndt_map_save / ndt_map_load): e.g. to resume a session without the keyframe clouds
+    std::vector<unsigned char> saveMap() {
+        size_t need = 0;
+        check(ndt_map_save(handle(), nullptr, 0, &need));
+        std::vector<unsigned char> blob(need);
+        check(ndt_map_save(handle(), blob.data(), blob.size(), &need));
+        return blob;
+    }
+    void loadMap(const std::vector<unsigned char>& blob) { check(ndt_map_load(handle(), blob.data(), blob.size())); }
     const ndt_result& result() const { return res_; }
     int status() const { return status_; }
     std::string lastError() const { return h_ ? ndt_last_error(h_) : "no handle"; }

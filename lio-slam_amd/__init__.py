@@ -23,7 +23,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
-    "ndt_export_voxels", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
+    "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
@@ -91,6 +91,8 @@ def lib():
     L.ndt_num_voxels.restype = C.c_int64
     L.ndt_num_voxels.argtypes = [vp]
     L.ndt_export_voxels.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.ndt_map_save.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.ndt_map_load.argtypes = [vp, vp, sz]
     L.ndt_information_from_hessian.argtypes = [vp, C.c_double, C.c_double, vp]
     L.ndt_pack_key.restype = C.c_int64
     L.ndt_pack_key.argtypes = [C.c_int32] * 3
@@ -279,6 +281,18 @@ class NDT:
         self._chk(lib().ndt_export_voxels(self._h, keys.ctypes.data, cnt.ctypes.data, mean.ctypes.data, cov.ctypes.data,
                                           info.ctypes.data, valid.ctypes.data, n, C.byref(no)))
         return dict(keys=keys, counts=cnt, mean=mean, cov=cov, info=info, valid=valid)
+
+    def save_map(self):
+        """The resident voxel map as bytes (layout: include/ndt_mi355.h, ndt_map_save)."""
+        need = C.c_size_t()
+        self._chk(lib().ndt_map_save(self._h, None, 0, C.byref(need)))
+        buf = np.zeros(need.value, np.uint8)
+        self._chk(lib().ndt_map_save(self._h, buf.ctypes.data, buf.nbytes, C.byref(need)))
+        return buf.tobytes()
+
+    def load_map(self, blob):
+        buf = np.frombuffer(blob, np.uint8)
+        self._chk(lib().ndt_map_load(self._h, buf.ctypes.data if len(buf) else None, len(buf)))
 
     # --- measurement helpers
     def profile(self, enable=True): self._chk(lib().ndt_profile(self._h, int(enable)))

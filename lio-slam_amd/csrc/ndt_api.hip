@@ -434,6 +434,88 @@ int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mea
     return NDT_OK;
 }
 
+// ---- map serialisation (layout in ndt_mi355.h)
+
+namespace {
+struct MapBlobHeader {
+    char magic[8];
+    uint32_t version;
+    float resolution;
+    int32_t key_rule;
+    int32_t reserved0;
+    uint64_t n_voxels;
+    unsigned char reserved[32];
+};
+static_assert(sizeof(MapBlobHeader) == 64, "map blob header is 64 bytes");
+const char MAP_MAGIC[8] = {'N', 'D', 'T', 'M', 'I', '3', '5', '5'};
+inline size_t map_blob_size(size_t n) { return sizeof(MapBlobHeader) + n * (8 + 24 + 48 + 4); }
+}  // namespace
+
+int ndt_map_save(ndt_handle* h, void* buf, size_t cap_bytes, size_t* n_bytes) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->have_target) { h->err = "no target"; return NDT_ERR_NO_TARGET; }
+    const size_t nv = (size_t)h->map.n_vox, need = map_blob_size(nv);
+    if (n_bytes) *n_bytes = need;
+    if (!buf) return NDT_OK;
+    if (cap_bytes < need) { h->err = "buffer smaller than the serialised map"; return NDT_ERR_CAPACITY; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    std::vector<int64_t> k; std::vector<int32_t> c; std::vector<double> m, cv;
+    int rc = map_dump(h->map, k, c, m, cv, h->stream, h->err);
+    if (rc != NDT_OK) return rc;
+    if (k.size() != nv) { h->err = "voxel count changed during the dump"; return NDT_ERR_HIP; }
+    MapBlobHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, MAP_MAGIC, 8);
+    hd.version = 1;
+    hd.resolution = (float)h->build_cfg.kp.res_d;
+    hd.key_rule = h->build_cfg.kp.key_rule;
+    hd.n_voxels = nv;
+    unsigned char* o = (unsigned char*)buf;
+    memcpy(o, &hd, sizeof hd); o += sizeof hd;
+    memcpy(o, k.data(), nv * 8); o += nv * 8;
+    memcpy(o, m.data(), nv * 24); o += nv * 24;
+    memcpy(o, cv.data(), nv * 48); o += nv * 48;
+    memcpy(o, c.data(), nv * 4);
+    return NDT_OK;
+}
+
+int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!buf || n_bytes < sizeof(MapBlobHeader)) { h->err = "map blob too short"; return NDT_ERR_INVALID_ARG; }
+    MapBlobHeader hd;
+    memcpy(&hd, buf, sizeof hd);
+    if (memcmp(hd.magic, MAP_MAGIC, 8) != 0 || hd.version != 1) { h->err = "not a version-1 NDTMI355 map blob"; return NDT_ERR_INVALID_ARG; }
+    if (hd.resolution != h->cfg.resolution || hd.key_rule != h->cfg.key_rule) {
+        h->err = "map blob was saved with another resolution or key_rule";
+        return NDT_ERR_INVALID_ARG;
+    }
+    if (hd.n_voxels >= (1ull << 31) || n_bytes != map_blob_size((size_t)hd.n_voxels)) { h->err = "map blob size does not match its header"; return NDT_ERR_INVALID_ARG; }
+    const size_t nv = (size_t)hd.n_voxels;
+    const unsigned char* in = (const unsigned char*)buf + sizeof hd;
+    std::vector<int64_t> k(nv); std::vector<double> m(nv * 3), cv(nv * 6); std::vector<int32_t> c(nv);
+    memcpy(k.data(), in, nv * 8); in += nv * 8;
+    memcpy(m.data(), in, nv * 24); in += nv * 24;
+    memcpy(cv.data(), in, nv * 48); in += nv * 48;
+    memcpy(c.data(), in, nv * 4);
+    for (size_t i = 0; i < nv; ++i) {      // a blob is untrusted input: the insert kernel relies on distinct in-range keys
+        int32_t x, y, z;
+        ndt_unpack(k[i], x, y, z);
+        const bool in_range = k[i] >= 0 && ndt_pack(x, y, z) == k[i];
+        if (!in_range || (i && k[i] <= k[i - 1]) || c[i] < 1) { h->err = "map blob holds an invalid, unsorted or duplicate key, or an empty voxel"; return NDT_ERR_INVALID_ARG; }
+    }
+    for (size_t i = 0; i < nv * 3; ++i) if (!std::isfinite(m[i])) { h->err = "map blob holds a non-finite mean"; return NDT_ERR_INVALID_ARG; }
+    for (size_t i = 0; i < nv * 6; ++i) if (!std::isfinite(cv[i])) { h->err = "map blob holds a non-finite covariance"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    H_TRY(map_clear(h->map, h->stream));
+    h->have_target = false;
+    h->build_cfg.kp = key_params(h->cfg);
+    h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
+    h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+    int rc = map_restore(h->map, h->work, h->build_cfg, k.data(), c.data(), m.data(), cv.data(), nv, h->stream, h->err);
+    if (rc == NDT_OK) h->have_target = true;
+    return rc;
+}
+
 // ---- the NDT Hessian as PointCloudFactor's information (host only, no GPU work)
 
 int ndt_information_from_hessian(const double H[36], double scale, double rel_floor, double info[36]) {

@@ -77,6 +77,10 @@ int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, siz
 int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& keys, std::vector<int32_t>& counts,
                std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
                std::vector<uint8_t>& valid, hipStream_t s, std::string& err);
+int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>& counts, std::vector<double>& mean, std::vector<double>& cov,
+             hipStream_t s, std::string& err);
+int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
+                size_t n, hipStream_t s, std::string& err);
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
 
 // ---- ndt_residual.hip

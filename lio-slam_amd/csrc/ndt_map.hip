@@ -551,11 +551,12 @@ __device__ inline bool neighbour_key(int64_t key, int d, int64_t* out) {   // d:
     return true;
 }
 // per batch voxel: how many of its six neighbours are not in the table yet (an upper bound of the ghosts to add)
-__global__ void k_ghost_count(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg, SortKeyMap km, const int64_t* keys,
+// the batch's voxels come either as sorted segments (sk, seg_start, km) or as a plain key list (plain != nullptr)
+__global__ void k_ghost_count(const uint64_t* sk, const uint32_t* seg_start, const int64_t* plain, uint32_t nseg, SortKeyMap km, const int64_t* keys,
                               uint64_t mask, uint32_t* missing) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nseg) return;
-    const int64_t key = sortkey_to_packed(sk[seg_start[g]], km);
+    const int64_t key = plain ? plain[g] : sortkey_to_packed(sk[seg_start[g]], km);
     uint32_t n = 0;
     for (int d = 0; d < 6; ++d) {
         int64_t nk;
@@ -563,11 +564,11 @@ __global__ void k_ghost_count(const uint64_t* sk, const uint32_t* seg_start, uin
     }
     missing[g] = n;
 }
-__global__ void k_ghost_insert(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg, SortKeyMap km, int64_t* keys,
+__global__ void k_ghost_insert(const uint64_t* sk, const uint32_t* seg_start, const int64_t* plain, uint32_t nseg, SortKeyMap km, int64_t* keys,
                                uint64_t mask, uint32_t* inserted) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nseg) return;
-    const int64_t key = sortkey_to_packed(sk[seg_start[g]], km);
+    const int64_t key = plain ? plain[g] : sortkey_to_packed(sk[seg_start[g]], km);
     uint32_t n = 0;
     for (int d = 0; d < 6; ++d) {
         int64_t nk;
@@ -620,6 +621,46 @@ static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::str
 }
 
 static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; return b; }
+
+// After the voxels of a batch are in the table: count the new voxels / entries (flags written by the insert kernel),
+// add the ghost cells around the batch's voxels and rewrite the neighbour links.
+static int finish_entries(VoxelMap& m, MapWork& w, const uint64_t* sorted_keys, const uint32_t* segs, const int64_t* plain, uint32_t nseg,
+                          const SortKeyMap& km, hipStream_t s, std::string& err) {
+    int rc;
+    // sums of per-voxel flags (block sums + one-block spine; no scan-down needed): misc[8..11]
+    uint32_t* d_sums = (uint32_t*)(w.misc.as<int32_t>() + 8);
+    const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
+    const unsigned nbseg = (unsigned)((nseg + 255) / 256);
+    HIP_TRY(w.scan_tmp.ensure((nbf + 2) * 4));
+    auto sum_flags = [&](const uint32_t* f, uint32_t* out) {
+        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(f, nseg, w.scan_tmp.as<uint32_t>());
+        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, out);
+    };
+    sum_flags(w.flags.as<uint32_t>(), d_sums + 0);      // new voxels
+    sum_flags(w.flags2.as<uint32_t>(), d_sums + 1);     // new table entries
+    k_ghost_count<<<nbseg, 256, 0, s>>>(sorted_keys, segs, plain, nseg, km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+    sum_flags(w.flags.as<uint32_t>(), d_sums + 2);      // neighbours not in the table yet (upper bound)
+    HIP_TRY(hipGetLastError());
+    uint32_t sums[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(sums, d_sums, 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m.n_vox += sums[0];
+    m.n_entries += sums[1];
+    if (sums[2]) {
+        rc = map_reserve(m, (size_t)m.n_entries + sums[2], s, err);
+        if (rc != NDT_OK) return rc;
+        k_ghost_insert<<<nbseg, 256, 0, s>>>(sorted_keys, segs, plain, nseg, km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
+        sum_flags(w.flags.as<uint32_t>(), d_sums + 3);
+    }
+    k_link_all<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.cap);
+    HIP_TRY(hipGetLastError());
+    if (sums[2]) {
+        HIP_TRY(hipMemcpyAsync(sums + 3, d_sums + 3, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m.n_entries += sums[3];
+    }
+    return NDT_OK;
+}
 
 // Stage 1 of every cloud ingest: (optional transform,) cell of every point, LSD radix sort of (cell, index),
 // segments (= cells) and the points gathered into sorted order (w.gx/gy/gz).  pts: AoS records in host or device
@@ -728,38 +769,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>());
     }
     HIP_TRY(hipGetLastError());
-    // sums of per-voxel flags (block sums + one-block spine; no scan-down needed): misc[8..11]
-    uint32_t* d_sums = (uint32_t*)(w.misc.as<int32_t>() + 8);
-    const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
-    const unsigned nbseg = (unsigned)((nseg + 255) / 256);
-    auto sum_flags = [&](const uint32_t* f, uint32_t* out) {
-        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(f, nseg, w.scan_tmp.as<uint32_t>());
-        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, out);
-    };
-    sum_flags(w.flags.as<uint32_t>(), d_sums + 0);      // new voxels
-    sum_flags(w.flags2.as<uint32_t>(), d_sums + 1);     // new table entries
-    k_ghost_count<<<nbseg, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
-    sum_flags(w.flags.as<uint32_t>(), d_sums + 2);      // neighbours not in the table yet (upper bound)
-    HIP_TRY(hipGetLastError());
-    uint32_t sums[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(sums, d_sums, 12, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    m.n_vox += sums[0];
-    m.n_entries += sums[1];
-    if (sums[2]) {
-        rc = map_reserve(m, (size_t)m.n_entries + sums[2], s, err);
-        if (rc != NDT_OK) return rc;
-        k_ghost_insert<<<nbseg, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
-        sum_flags(w.flags.as<uint32_t>(), d_sums + 3);
-    }
-    k_link_all<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.cap);
-    HIP_TRY(hipGetLastError());
-    if (sums[2]) {
-        HIP_TRY(hipMemcpyAsync(sums + 3, d_sums + 3, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        m.n_entries += sums[3];
-    }
-    return NDT_OK;
+    return finish_entries(m, w, sc.sorted_keys, segs, nullptr, nseg, sc.km, s, err);
 }
 
 // Scan pre-processing: pcl::transformPointCloud + pcl::VoxelGrid(leaf) of process.cc:62-73 —
@@ -842,4 +852,95 @@ int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& key
         }
     }
     return NDT_OK;
+}
+
+// ------------------------------------------------------------------ serialised maps
+// A saved map is the exact per-voxel state (key, count, float64 mean offset and covariance); loading re-inserts the
+// voxels and derives the float32 payload with the same finalize_slot, so a loaded map answers bit for bit like the
+// map that was saved, and later merges continue from the same statistics.
+__global__ void k_import(const int64_t* in_keys, const int32_t* in_counts, const double* in_mean, const double* in_cov, uint32_t n, MapBuildCfg cfg,
+                         VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
+                         uint32_t* entry_flag) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const int64_t key = in_keys[g];
+    uint64_t slot = ndt_hash_key(key) & mask;
+    bool fresh = false;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
+        if ((int64_t)prev == NDT_KEY_EMPTY) { fresh = true; break; }
+        if ((int64_t)prev == key) break;          // cannot happen for a validated file into a cleared map
+        slot = (slot + 1) & mask;
+    }
+    if (fresh && slot < 4) keys[mask + 1 + slot] = key;
+    entry_flag[g] = fresh ? 1u : 0u;
+    fresh_flag[g] = 1u;
+    double mu[3], cv[6];
+    for (int j = 0; j < 3; ++j) { mu[j] = in_mean[(size_t)g * 3 + j]; mean[slot * 3 + j] = mu[j]; }
+    for (int j = 0; j < 6; ++j) { cv[j] = in_cov[(size_t)g * 6 + j]; cov[slot * 6 + j] = cv[j]; }
+    counts[slot] = in_counts[g];
+    finalize_slot(&slots[slot], in_counts[g], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+}
+
+__global__ void k_export_raw(const int64_t* keys, const int32_t* counts, const double* mean, const double* cov, size_t cap, uint32_t* counter,
+                             int64_t* okeys, int32_t* ocounts, double* omean, double* ocov) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    if (keys[i] == NDT_KEY_EMPTY || counts[i] == 0) return;
+    uint32_t o = atomicAdd(counter, 1u);
+    okeys[o] = keys[i]; ocounts[o] = counts[i];
+    for (int j = 0; j < 3; ++j) omean[(size_t)o * 3 + j] = mean[i * 3 + j];
+    for (int j = 0; j < 6; ++j) ocov[(size_t)o * 6 + j] = cov[i * 6 + j];
+}
+
+// raw per-voxel state in ascending key order (host vectors)
+int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>& counts, std::vector<double>& mean, std::vector<double>& cov,
+             hipStream_t s, std::string& err) {
+    const size_t nv = (size_t)m.n_vox;
+    keys.assign(nv, 0); counts.assign(nv, 0); mean.assign(nv * 3, 0); cov.assign(nv * 6, 0);
+    if (!nv) return NDT_OK;
+    DevBuf dcnt, dm, dc, dk, dn;
+    HIP_TRY(dcnt.ensure(4)); HIP_TRY(dm.ensure(nv * 24)); HIP_TRY(dc.ensure(nv * 48)); HIP_TRY(dk.ensure(nv * 8)); HIP_TRY(dn.ensure(nv * 4));
+    HIP_TRY(hipMemsetAsync(dcnt.p, 0, 4, s));
+    k_export_raw<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.counts, m.mean, m.cov, m.cap, dcnt.as<uint32_t>(), dk.as<int64_t>(),
+                                                                 dn.as<int32_t>(), dm.as<double>(), dc.as<double>());
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> hk(nv); std::vector<int32_t> hn(nv); std::vector<double> hm(nv * 3), hc(nv * 6);
+    HIP_TRY(hipMemcpyAsync(hk.data(), dk.p, nv * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hn.data(), dn.p, nv * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hm.data(), dm.p, nv * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hc.data(), dc.p, nv * 48, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    dcnt.release(); dm.release(); dc.release(); dk.release(); dn.release();
+    std::vector<size_t> ord(nv);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
+    for (size_t o = 0; o < nv; ++o) {
+        const size_t i = ord[o];
+        keys[o] = hk[i]; counts[o] = hn[i];
+        for (int j = 0; j < 3; ++j) mean[o * 3 + j] = hm[i * 3 + j];
+        for (int j = 0; j < 6; ++j) cov[o * 6 + j] = hc[i * 6 + j];
+    }
+    return NDT_OK;
+}
+
+// the inverse: n voxels (distinct keys, host arrays) into a cleared map
+int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
+                size_t n, hipStream_t s, std::string& err) {
+    if (n >= (1ull << 31)) { err = "more than 2^31 voxels"; return NDT_ERR_INVALID_ARG; }
+    int rc = map_reserve(m, n ? n : 1, s, err);
+    if (rc != NDT_OK || n == 0) return rc;
+    HIP_TRY(w.misc.ensure(256));
+    HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4)); HIP_TRY(w.keys_b.ensure(n * 24)); HIP_TRY(w.raw.ensure(n * 48));
+    HIP_TRY(w.flags.ensure(n * 4)); HIP_TRY(w.flags2.ensure(n * 4 + 16));
+    HIP_TRY(hipMemcpyAsync(w.keys_a.p, keys, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.vals_a.p, counts, n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.keys_b.p, mean, n * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.raw.p, cov, n * 48, hipMemcpyHostToDevice, s));
+    k_import<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(w.keys_a.as<int64_t>(), w.vals_a.as<int32_t>(), w.keys_b.as<double>(), w.raw.as<double>(), (uint32_t)n,
+                                                         cfg, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(),
+                                                         w.flags2.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    SortKeyMap km{};
+    return finish_entries(m, w, nullptr, nullptr, w.keys_a.as<int64_t>(), (uint32_t)n, km, s, err);
 }
