@@ -178,6 +178,57 @@ int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes);
  * rank-deficient) and `Eigen::LLT(info)` at src/slam/include/factor.h:224 cannot fail.  Host-only. */
 int ndt_information_from_hessian(const double H[36], double scale, double rel_floor, double info[36]);
 
+/* ---- SURVEY.md §8(f) row N4 — PCL compatibility mode ------------------------------------------------------
+ * The objective, derivatives and optimiser the reference's live build executes behind ndt_.align()
+ * (src/slam/src/process.cc:94; parameters process.cc:373-376): pcl::NormalDistributionsTransform of PCL >= 1.12
+ * (README.md:52 names PCL 1.14) as restated in SURVEY.md Appendix A — the PCL sources are not in this image, so
+ * this mode is "parity unpinned" like the rest:
+ *   - transform vector p = [tx ty tz, rx ry rz], R = Rx(rx) Ry(ry) Rz(rz) (Eigen eulerAngles(0,1,2));
+ *   - the source cloud is transformed in float32 (PCL's Scalar = float);
+ *   - neighbours of a transformed point = voxels with >= min_pts_in_voxel points whose centroid lies within
+ *     `resolution` of it (radius search on the centroid kd-tree; here: the 27 cells around the point's cell + the
+ *     distance test, which gives the same set);
+ *   - score = sum -d1 exp(-d2/2 x'^T C x'), gradient and Hessian of Magnusson 2009 eq. 6.12 / 6.13 with the
+ *     Gaussian constants d1, d2 from outlier_ratio and resolution;
+ *   - Newton direction from an SVD solve, More-Thuente line search (mu 1e-4, nu 0.9, <= 10 trials) between
+ *     eps/2 and step_size, convergence when iterations >= max_iterations or |dt|^2 <= eps (PCL compares the
+ *     SQUARED translation with eps) and, if rotation_eps > 0, cos(angle) >= rotation_eps.
+ * Uses the handle's resolution, max_iterations, eps and the resident map / source; `nearby`, `res_outlier_th` and
+ * `min_effective_pts` do not apply. */
+typedef struct ndt_pcl_params {
+    double outlier_ratio;        /* 0.55, PCL's default (the reference never sets it)                        */
+    double step_size;            /* 0.1, ndt_.setStepSize(0.1) at process.cc:376: More-Thuente maximum step  */
+    double rotation_eps;         /* 0: transformation_rotation_epsilon_ is left unset by the reference       */
+    int32_t hessian_d1_as_pcl;   /* 1: row d1 of the angular Hessian as PCL has it (+sin ry in its third
+                                    entry); 0: Magnusson eq. 6.21 (-sin ry)                                  */
+    int32_t reserved;
+} ndt_pcl_params;
+
+typedef struct ndt_pcl_result {
+    double T[16];                /* final transform, column-major                                            */
+    double p[6];                 /* final transform vector                                                   */
+    double score;                /* PCL's score at the final transform                                       */
+    double trans_probability;    /* getTransformationProbability(): score / number of source points          */
+    double gradient[6];          /* score gradient and Hessian at the final transform (row-major 6x6)        */
+    double hessian[36];
+    int64_t n_neighbours;        /* (point, voxel) pairs in the last evaluation                              */
+    int32_t iterations;          /* getFinalNumIteration()                                                   */
+    int32_t converged;           /* hasConverged()                                                           */
+    int32_t status;
+    int32_t evaluations;         /* passes over the source cloud (derivative + Hessian-only evaluations)     */
+} ndt_pcl_result;
+
+void ndt_pcl_default_params(ndt_pcl_params* prm);
+/* One computeDerivatives pass at transform vector p: score, gradient g[6], Hessian H[36] (row-major; skipped when
+ * H == NULL), number of (point, voxel) pairs.  The unit the parity tests call. */
+int ndt_pcl_eval(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], double* score, double g[6], double H[36],
+                 int64_t* n_neighbours);
+/* computeTransformation from `guess` (column-major 4x4).  NDT_OK also when the iteration cap ended the loop. */
+int ndt_pcl_align(ndt_handle* h, const ndt_pcl_params* prm, const double guess[16], ndt_pcl_result* out);
+/* Host helpers of the mode: p <-> matrix (Eigen's eulerAngles(0,1,2) convention, first angle in [0, pi]). */
+void ndt_pcl_vector_from_matrix(const double T[16], double p[6]);
+void ndt_pcl_matrix_from_vector(const double p[6], double T[16]);
+
 /* Packed-key helpers (21 bits per axis, biased by 2^20). */
 int64_t ndt_pack_key(int32_t ix, int32_t iy, int32_t iz);
 void ndt_unpack_key(int64_t key, int32_t* ix, int32_t* iy, int32_t* iz);

@@ -23,7 +23,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
-    "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
+    "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
@@ -42,6 +42,17 @@ class Config(C.Structure):
         ("min_effective_pts", C.c_int32), ("key_rule", C.c_int32), ("eig_floor_ratio", C.c_double),
         ("final_eval", C.c_int32), ("device", C.c_int32),
     ]
+
+
+class PclParams(C.Structure):
+    _fields_ = [("outlier_ratio", C.c_double), ("step_size", C.c_double), ("rotation_eps", C.c_double),
+                ("hessian_d1_as_pcl", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PclResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("p", C.c_double * 6), ("score", C.c_double), ("trans_probability", C.c_double),
+                ("gradient", C.c_double * 6), ("hessian", C.c_double * 36), ("n_neighbours", C.c_int64),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("status", C.c_int32), ("evaluations", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -91,6 +102,11 @@ def lib():
     L.ndt_num_voxels.restype = C.c_int64
     L.ndt_num_voxels.argtypes = [vp]
     L.ndt_export_voxels.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.ndt_pcl_default_params.argtypes = [C.POINTER(PclParams)]
+    L.ndt_pcl_eval.argtypes = [vp, C.POINTER(PclParams), vp, vp, vp, vp, vp]
+    L.ndt_pcl_align.argtypes = [vp, C.POINTER(PclParams), vp, C.POINTER(PclResult)]
+    L.ndt_pcl_vector_from_matrix.argtypes = [vp, vp]
+    L.ndt_pcl_matrix_from_vector.argtypes = [vp, vp]
     L.ndt_map_save.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.ndt_map_load.argtypes = [vp, vp, sz]
     L.ndt_information_from_hessian.argtypes = [vp, C.c_double, C.c_double, vp]
@@ -282,6 +298,35 @@ class NDT:
                                           info.ctypes.data, valid.ctypes.data, n, C.byref(no)))
         return dict(keys=keys, counts=cnt, mean=mean, cov=cov, info=info, valid=valid)
 
+    # --- PCL compatibility mode
+    @staticmethod
+    def pcl_params(**kw):
+        prm = PclParams()
+        lib().ndt_pcl_default_params(C.byref(prm))
+        for k, v in kw.items():
+            if not hasattr(prm, k):
+                raise AttributeError(k)
+            setattr(prm, k, v)
+        return prm
+
+    def pcl_eval(self, p, hessian=True, **prm):
+        """One computeDerivatives pass at transform vector p = [t, euler xyz]: score, gradient, Hessian."""
+        p = np.ascontiguousarray(p, np.float64); g = np.zeros(6); H = np.zeros((6, 6))
+        sc = C.c_double(); nb = C.c_int64(); pr = self.pcl_params(**prm)
+        self._chk(lib().ndt_pcl_eval(self._h, C.byref(pr), p.ctypes.data, C.addressof(sc), g.ctypes.data,
+                                     H.ctypes.data if hessian else None, C.addressof(nb)))
+        return dict(score=sc.value, g=g, H=H if hessian else None, n_neighbours=nb.value)
+
+    def pcl_align(self, guess, **prm):
+        """pcl::NormalDistributionsTransform::computeTransformation (Newton + More-Thuente) from `guess`."""
+        t = _T(guess); r = PclResult(); pr = self.pcl_params(**prm)
+        rc = lib().ndt_pcl_align(self._h, C.byref(pr), t.ctypes.data, C.byref(r))
+        if rc in (-1, -2, -3, -4):
+            self._chk(rc)
+        return dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), p=np.array(r.p), score=r.score,
+                    trans_probability=r.trans_probability, g=np.array(r.gradient), H=np.array(r.hessian).reshape(6, 6),
+                    n_neighbours=r.n_neighbours, iterations=r.iterations, converged=bool(r.converged), evaluations=r.evaluations)
+
     def save_map(self):
         """The resident voxel map as bytes (layout: include/ndt_mi355.h, ndt_map_save)."""
         need = C.c_size_t()
@@ -346,3 +391,16 @@ def unpack_keys(keys):
     k = np.asarray(keys, np.int64)
     b = 1 << 20
     return np.stack([((k >> 42) & 0x1FFFFF) - b, ((k >> 21) & 0x1FFFFF) - b, (k & 0x1FFFFF) - b], 1).astype(np.int32)
+
+
+def pcl_vector_from_matrix(T):
+    """[t, euler xyz] of a 4x4 pose in Eigen's eulerAngles(0,1,2) convention (host only)."""
+    t = _T(T); p = np.zeros(6)
+    lib().ndt_pcl_vector_from_matrix(t.ctypes.data, p.ctypes.data)
+    return p
+
+
+def pcl_matrix_from_vector(p):
+    p = np.ascontiguousarray(p, np.float64); t = np.zeros(16)
+    lib().ndt_pcl_matrix_from_vector(p.ctypes.data, t.ctypes.data)
+    return t.reshape(4, 4).T.copy()

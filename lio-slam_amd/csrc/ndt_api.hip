@@ -53,7 +53,7 @@ struct ndt_handle {
     DevBuf sx, sy, sz, sraw;
     size_t n_src = 0;
     bool have_source = false;
-    DevBuf partials, cell_keys, cell_mask;
+    DevBuf partials, cell_keys, cell_mask, pcl_partials;
     GnState* d_state = nullptr;
     GnState* h_state = nullptr;  // pinned
     std::string err;
@@ -514,6 +514,52 @@ int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes) {
     int rc = map_restore(h->map, h->work, h->build_cfg, k.data(), c.data(), m.data(), cv.data(), nv, h->stream, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;
+}
+
+// ---- PCL compatibility mode (kernels and driver in ndt_pcl.hip)
+
+void ndt_pcl_default_params(ndt_pcl_params* p) {
+    if (!p) return;
+    p->outlier_ratio = 0.55; p->step_size = 0.1; p->rotation_eps = 0.0; p->hessian_d1_as_pcl = 1; p->reserved = 0;
+}
+void ndt_pcl_vector_from_matrix(const double T[16], double p[6]) { if (T && p) pcl_vector_from_matrix(T, p); }
+void ndt_pcl_matrix_from_vector(const double p[6], double T[16]) { if (T && p) pcl_matrix_from_vector(p, T); }
+
+static int pcl_engine(ndt_handle* h, const ndt_pcl_params* prm, PclEngine* e) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!prm || !(prm->outlier_ratio > 0.0) || !(prm->outlier_ratio < 1.0) || !(prm->step_size > 0.0)) {
+        h->err = "PCL-mode parameters: outlier_ratio must be in (0,1) and step_size positive";
+        return NDT_ERR_INVALID_ARG;
+    }
+    H_TRY(hipSetDevice(h->cfg.device));
+    H_TRY(h->pcl_partials.ensure(((size_t)pcl_grid(h->n_src) + 1) * ACC_N * sizeof(double)));
+    e->stream = h->stream;
+    e->keys = h->map.keys; e->slots = h->map.slots; e->mask = (uint32_t)(h->map.cap - 1);
+    e->sx = h->sx.as<float>(); e->sy = h->sy.as<float>(); e->sz = h->sz.as<float>(); e->n = h->n_src;
+    e->kp = h->build_cfg.kp;
+    e->partials = h->pcl_partials.as<double>() + ACC_N;
+    e->d_row = h->pcl_partials.as<double>();
+    e->h_row = h->h_state->acc;          // pinned; the Gauss-Newton loop is not running while this mode is
+    return NDT_OK;
+}
+
+int ndt_pcl_eval(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], double* score, double g[6], double H[36], int64_t* n_neighbours) {
+    if (!h || !p) return NDT_ERR_INVALID_ARG;
+    PclEngine e;
+    int rc = pcl_engine(h, prm, &e);
+    if (rc != NDT_OK) return rc;
+    for (int k = 0; k < 6; ++k) if (!std::isfinite(p[k])) { h->err = "non-finite transform vector"; return NDT_ERR_INVALID_ARG; }
+    return pcl_eval(e, *prm, p, score, g, H, n_neighbours, h->err);
+}
+
+int ndt_pcl_align(ndt_handle* h, const ndt_pcl_params* prm, const double guess[16], ndt_pcl_result* out) {
+    if (!h || !guess || !out) return NDT_ERR_INVALID_ARG;
+    PclEngine e;
+    int rc = pcl_engine(h, prm, &e);
+    if (rc != NDT_OK) { memset(out, 0, sizeof *out); out->status = rc; return rc; }
+    for (int k = 0; k < 16; ++k) if (!std::isfinite(guess[k])) { h->err = "non-finite guess"; return NDT_ERR_INVALID_ARG; }
+    return pcl_align(e, *prm, h->cfg.max_iterations, h->cfg.eps, guess, out, h->err);
 }
 
 // ---- the NDT Hessian as PointCloudFactor's information (host only, no GPU work)

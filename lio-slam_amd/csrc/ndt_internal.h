@@ -81,6 +81,23 @@ int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>
              hipStream_t s, std::string& err);
 int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
                 size_t n, hipStream_t s, std::string& err);
+
+// ---- PCL compatibility mode (ndt_pcl.hip)
+struct PclEngine {            // what a pass needs from the handle
+    hipStream_t stream;
+    const int64_t* keys; const VoxSlot* slots; uint32_t mask;
+    const float *sx, *sy, *sz; size_t n;
+    KeyParams kp;
+    double* partials;         // pcl_grid(n) rows of ACC_N doubles
+    double* d_row;            // ACC_N doubles, device
+    double* h_row;            // ACC_N doubles, pinned host
+};
+int pcl_grid(size_t n);
+void pcl_matrix_from_vector(const double p[6], double T[16]);
+void pcl_vector_from_matrix(const double T[16], double p[6]);
+int pcl_eval(const PclEngine& e, const ndt_pcl_params& prm, const double p[6], double* score, double g[6], double* H, int64_t* n_nb, std::string& err);
+int pcl_align(const PclEngine& e, const ndt_pcl_params& prm, int max_iterations, double trans_eps, const double guess[16], ndt_pcl_result* out,
+              std::string& err);
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
 
 // ---- ndt_residual.hip

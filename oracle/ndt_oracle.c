@@ -703,3 +703,399 @@ int64_t ora_pack_key(int32_t x, int32_t y, int32_t z) { return pack_key(x, y, z)
 /* key of a single map point / of a single transformed source coordinate, for the key-rule vectors */
 int ora_target_key(ora_handle* h, const float p[3], int32_t c[3]) { return target_cell(h, p, c); }
 int ora_source_key(ora_handle* h, const double q[3], int32_t c[3]) { return source_cell(h, q, c); }
+
+/* ================================================================================================
+ * PCL compatibility mode.  TEST INFRASTRUCTURE ONLY, PARITY UNPINNED: PCL's sources are not
+ * in this image; what follows restates pcl::NormalDistributionsTransform (PCL >= 1.12 registration/impl/ndt.hpp:
+ * computeTransformation, computeDerivatives, computeAngleDerivatives, computePointDerivatives, updateDerivatives,
+ * computeHessian/updateHessian, computeStepLengthMT, trialValueSelectionMT, updateIntervalMT) and the radius search
+ * of VoxelGridCovariance as written down in SURVEY.md Appendix A.3-A.6 — the code src/slam/src/process.cc:94
+ * runs.  It is written the way PCL writes it (per neighbour, full 3x6 point Jacobian and 18x6 point Hessian,
+ * 6x6 double loop); the HIP engine sums the same terms per point in factored form, so this file also checks that
+ * algebra.  Arithmetic shared with the engine: the float32 transform matrix and transformed points, the cell rule
+ * and the float32 centroid distance test.
+ * ================================================================================================ */
+
+#include <float.h>
+
+void ora_pcl_default_params(ndt_pcl_params* p) {
+    p->outlier_ratio = 0.55; p->step_size = 0.1; p->rotation_eps = 0.0; p->hessian_d1_as_pcl = 1; p->reserved = 0;
+}
+
+/* eq. 6.8 [Magnusson 2009], computeTransformation() */
+static void pcl_gauss(double res, double outlier_ratio, double* d1, double* d2) {
+    const double c1 = 10.0 * (1.0 - outlier_ratio);
+    const double c2 = outlier_ratio / pow(res, 3);
+    const double d3 = -log(c2);
+    *d1 = -log(c1 + c2) - d3;
+    *d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / *d1);
+}
+
+/* R = Rx(p3) Ry(p4) Rz(p5), t = p0..2  (convertTransform) */
+static void pcl_rt_from_vector(const double p[6], double R[3][3], double t[3]) {
+    const double cx = cos(p[3]), sx = sin(p[3]), cy = cos(p[4]), sy = sin(p[4]), cz = cos(p[5]), sz = sin(p[5]);
+    R[0][0] = cy * cz;                  R[0][1] = -(cy * sz);               R[0][2] = sy;
+    R[1][0] = cx * sz + (sx * sy) * cz; R[1][1] = cx * cz - (sx * sy) * sz; R[1][2] = -(sx * cy);
+    R[2][0] = sx * sz - (cx * sy) * cz; R[2][1] = sx * cz + (cx * sy) * sz; R[2][2] = cx * cy;
+    t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+}
+void ora_pcl_matrix_from_vector(const double p[6], double T[16]) {
+    double R[3][3], t[3];
+    pcl_rt_from_vector(p, R, t);
+    T_from_mat(R, t, T);
+}
+/* Eigen's MatrixBase::eulerAngles(0,1,2): first angle in [0, pi] */
+void ora_pcl_vector_from_matrix(const double T[16], double p[6]) {
+    double m[3][3], t[3];
+    mat_from_T(T, m, t);
+    const double PI = 3.14159265358979323846;
+    double r0 = atan2(m[1][2], m[2][2]);
+    const double c2 = sqrt(m[0][0] * m[0][0] + m[0][1] * m[0][1]);
+    double r1;
+    if (r0 > 0.0) { r0 -= PI; r1 = atan2(-m[0][2], -c2); }
+    else r1 = atan2(-m[0][2], c2);
+    const double s1 = sin(r0), c1 = cos(r0);
+    const double r2 = atan2(s1 * m[2][0] - c1 * m[1][0], c1 * m[1][1] - s1 * m[2][1]);
+    p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+    p[3] = -r0; p[4] = -r1; p[5] = -r2;
+}
+
+static void pcl_cos_sin(double a, double* c, double* s) {
+    if (fabs(a) < 10e-5) { *c = 1.0; *s = 0.0; } else { *c = cos(a); *s = sin(a); }
+}
+/* computeAngleDerivatives: rows a..h of eq. 6.19 and a2..f3 of eq. 6.21 */
+static void pcl_angle_jacobian(const double p[6], double aj[8][3]) {
+    double cx, cy, cz, sx, sy, sz;
+    pcl_cos_sin(p[3], &cx, &sx); pcl_cos_sin(p[4], &cy, &sy); pcl_cos_sin(p[5], &cz, &sz);
+    const double v[8][3] = {
+        {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)},   /* a */
+        {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},     /* b */
+        {(-sy * cz), sy * sz, cy},                                            /* c */
+        {sx * cy * cz, (-sx * cy * sz), sx * sy},                             /* d */
+        {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},                          /* e */
+        {(-cy * sz), (-cy * cz), 0},                                          /* f */
+        {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0},             /* g */
+        {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};             /* h */
+    memcpy(aj, v, sizeof v);
+}
+static void pcl_angle_hessian(const double p[6], int d1_as_pcl, double ah[15][3]) {
+    double cx, cy, cz, sx, sy, sz;
+    pcl_cos_sin(p[3], &cx, &sx); pcl_cos_sin(p[4], &cy, &sy); pcl_cos_sin(p[5], &cz, &sz);
+    const double v[15][3] = {
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy},      /* a2 */
+        {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},   /* a3 */
+        {(cx * cy * cz), (-cx * cy * sz), (cx * sy)},                         /* b2 */
+        {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},                         /* b3 */
+        {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0},             /* c2 */
+        {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},             /* c3 */
+        {(-cy * cz), (cy * sz), d1_as_pcl ? (sy) : (-sy)},                    /* d1: PCL writes +sy; eq. 6.21 has -sy */
+        {(-sx * sy * cz), (sx * sy * sz), (sx * cy)},                         /* d2 */
+        {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},                        /* d3 */
+        {(sy * sz), (sy * cz), 0},                                            /* e1 */
+        {(-sx * cy * sz), (-sx * cy * cz), 0},                                /* e2 */
+        {(cx * cy * sz), (cx * cy * cz), 0},                                  /* e3 */
+        {(-cy * cz), (cy * sz), 0},                                           /* f1 */
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0},            /* f2 */
+        {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};           /* f3 */
+    memcpy(ah, v, sizeof v);
+}
+
+/* One pass over the source: computeDerivatives (with_gradient) or computeHessian (Hessian only).
+ * aj / ah are passed in because PCL refreshes the angular Hessian only when compute_hessian is true. */
+static double pcl_pass(const ora_handle* h, double d1, double d2, const double p[6], const double aj[8][3], const double ah[15][3],
+                       int with_gradient, int with_hessian, double g[6], double H[36], int64_t* n_nb) {
+    double R[3][3], t[3];
+    pcl_rt_from_vector(p, R, t);
+    float M[3][4];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M[r][c] = (float)R[r][c]; M[r][3] = (float)t[r]; }
+    const float r2f = (float)(h->res_d * h->res_d);
+    double score = 0.0;
+    int64_t nb = 0;
+    if (with_gradient) memset(g, 0, 6 * sizeof(double));
+    if (with_hessian) memset(H, 0, 36 * sizeof(double));
+    for (size_t i = 0; i < h->n_src; ++i) {
+        const float* x = h->src + 3 * i;
+        float q[3];
+        for (int r = 0; r < 3; ++r) q[r] = ((M[r][0] * x[0] + M[r][1] * x[1]) + M[r][2] * x[2]) + M[r][3];
+        if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) continue;
+        int32_t c[3];
+        if (!target_cell(h, q, c)) continue;
+        /* computePointDerivatives(x): J_E (3x6) and H_E (18x6) from the ORIGINAL point */
+        double J[3][6], HE[18][6];
+        memset(J, 0, sizeof J); memset(HE, 0, sizeof HE);
+        J[0][0] = J[1][1] = J[2][2] = 1.0;
+        double xa[8], xh[15];
+        for (int k = 0; k < 8; ++k) xa[k] = (aj[k][0] * x[0] + aj[k][1] * x[1]) + aj[k][2] * x[2];
+        J[1][3] = xa[0]; J[2][3] = xa[1]; J[0][4] = xa[2]; J[1][4] = xa[3]; J[2][4] = xa[4]; J[0][5] = xa[5]; J[1][5] = xa[6]; J[2][5] = xa[7];
+        if (with_hessian) {
+            for (int k = 0; k < 15; ++k) xh[k] = (ah[k][0] * x[0] + ah[k][1] * x[1]) + ah[k][2] * x[2];
+            const double va[3] = {0, xh[0], xh[1]}, vb[3] = {0, xh[2], xh[3]}, vc[3] = {0, xh[4], xh[5]};
+            const double* vd = xh + 6; const double* ve = xh + 9; const double* vf = xh + 12;
+            for (int r = 0; r < 3; ++r) {
+                HE[9 + r][3] = va[r];  HE[12 + r][3] = vb[r]; HE[15 + r][3] = vc[r];
+                HE[9 + r][4] = vb[r];  HE[12 + r][4] = vd[r]; HE[15 + r][4] = ve[r];
+                HE[9 + r][5] = vc[r];  HE[12 + r][5] = ve[r]; HE[15 + r][5] = vf[r];
+            }
+        }
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int32_t n0 = c[0] + dx, n1 = c[1] + dy, n2 = c[2] + dz;
+                    if (!in_range(n0) || !in_range(n1) || !in_range(n2)) continue;
+                    const int32_t vi = map_find(h, pack_key(n0, n1, n2));
+                    if (vi < 0) continue;
+                    const ora_voxel* v = &h->vox[vi];
+                    if (!v->valid) continue;
+                    /* radiusSearch(point, resolution) on the centroid cloud: float32 squared distance, strictly inside */
+                    const float cen[3] = {(float)((double)n0 * h->res_d + v->pay_off[0]), (float)((double)n1 * h->res_d + v->pay_off[1]),
+                                          (float)((double)n2 * h->res_d + v->pay_off[2])};
+                    const float e0 = q[0] - cen[0], e1 = q[1] - cen[1], e2 = q[2] - cen[2];
+                    const float dist2 = (e0 * e0 + e1 * e1) + e2 * e2;
+                    if (!(dist2 < r2f)) continue;
+                    ++nb;
+                    const double xt[3] = {((double)q[0] - (double)n0 * h->res_d) - v->pay_off[0], ((double)q[1] - (double)n1 * h->res_d) - v->pay_off[1],
+                                          ((double)q[2] - (double)n2 * h->res_d) - v->pay_off[2]};
+                    const double* I = v->pay_info;
+                    const double Ci[3][3] = {{I[0], I[1], I[2]}, {I[1], I[3], I[4]}, {I[2], I[4], I[5]}};
+                    double cx[3];
+                    for (int r = 0; r < 3; ++r) cx[r] = (Ci[r][0] * xt[0] + Ci[r][1] * xt[1]) + Ci[r][2] * xt[2];
+                    const double qv = (xt[0] * cx[0] + xt[1] * cx[1]) + xt[2] * cx[2];
+                    double e = exp(-d2 * qv / 2.0);
+                    const double score_inc = -d1 * e;
+                    e = d2 * e;
+                    if (e > 1.0 || e < 0.0 || isnan(e)) continue;       /* updateDerivatives returns 0: no score either */
+                    if (with_gradient) score += score_inc;
+                    e *= d1;
+                    for (int a = 0; a < 6; ++a) {
+                        double cj[3];
+                        for (int r = 0; r < 3; ++r) cj[r] = (Ci[r][0] * J[0][a] + Ci[r][1] * J[1][a]) + Ci[r][2] * J[2][a];
+                        const double xcj = (xt[0] * cj[0] + xt[1] * cj[1]) + xt[2] * cj[2];
+                        if (with_gradient) g[a] += xcj * e;
+                        if (!with_hessian) continue;
+                        for (int b = 0; b < 6; ++b) {
+                            double cjb[3], ch[3];
+                            for (int r = 0; r < 3; ++r) {
+                                cjb[r] = (Ci[r][0] * J[0][b] + Ci[r][1] * J[1][b]) + Ci[r][2] * J[2][b];
+                                ch[r] = (Ci[r][0] * HE[3 * a][b] + Ci[r][1] * HE[3 * a + 1][b]) + Ci[r][2] * HE[3 * a + 2][b];
+                            }
+                            const double xcjb = (xt[0] * cjb[0] + xt[1] * cjb[1]) + xt[2] * cjb[2];
+                            const double xch = (xt[0] * ch[0] + xt[1] * ch[1]) + xt[2] * ch[2];
+                            const double jcj = (J[0][b] * cj[0] + J[1][b] * cj[1]) + J[2][b] * cj[2];
+                            H[a * 6 + b] += e * (-d2 * xcj * xcjb + xch + jcj);
+                        }
+                    }
+                }
+    }
+    if (n_nb) *n_nb = nb;
+    return score;
+}
+
+int ora_pcl_eval(ora_handle* h, const ndt_pcl_params* prm, const double p[6], double* score, double g[6], double H[36], int64_t* n_nb) {
+    if (!h->n_vox) return NDT_ERR_NO_TARGET;
+    if (!h->src) return NDT_ERR_NO_SOURCE;
+    double d1, d2, aj[8][3], ah[15][3], gg[6], HH[36];
+    pcl_gauss(h->res_d, prm->outlier_ratio, &d1, &d2);
+    pcl_angle_jacobian(p, aj); pcl_angle_hessian(p, prm->hessian_d1_as_pcl, ah);
+    const double s = pcl_pass(h, d1, d2, p, aj, ah, 1, H != NULL, gg, HH, n_nb);
+    if (score) *score = s;
+    if (g) memcpy(g, gg, sizeof gg);
+    if (H) memcpy(H, HH, sizeof HH);
+    return NDT_OK;
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric 6x6 (A = V diag(lam) V^T; V row-major, columns = vectors) */
+static void sym6_eig(const double Ain[36], double lam[6], double V[36]) {
+    double A[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { A[i][j] = 0.5 * (Ain[i * 6 + j] + Ain[j * 6 + i]); V[i * 6 + j] = (i == j); }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < 6; ++i) { dia += A[i][i] * A[i][i]; for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j]; }
+        if (off <= 1e-32 * dia || off == 0.0) break;
+        for (int pp = 0; pp < 5; ++pp)
+            for (int qq = pp + 1; qq < 6; ++qq) {
+                if (A[pp][qq] == 0.0) continue;
+                const double th = (A[qq][qq] - A[pp][pp]) / (2.0 * A[pp][qq]);
+                const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 6; ++k) { const double a = A[k][pp], b = A[k][qq]; A[k][pp] = c * a - s * b; A[k][qq] = s * a + c * b; }
+                for (int k = 0; k < 6; ++k) { const double a = A[pp][k], b = A[qq][k]; A[pp][k] = c * a - s * b; A[qq][k] = s * a + c * b; }
+                for (int k = 0; k < 6; ++k) { const double a = V[k * 6 + pp], b = V[k * 6 + qq]; V[k * 6 + pp] = c * a - s * b; V[k * 6 + qq] = s * a + c * b; }
+            }
+    }
+    for (int i = 0; i < 6; ++i) lam[i] = A[i][i];
+}
+/* JacobiSVD(H).solve(b) for a symmetric H: pseudo-inverse over the eigenvalues above Eigen's default rank threshold */
+static void pcl_svd_solve(const double H[36], const double b[6], double x[6]) {
+    double lam[6], V[36], mx = 0.0;
+    sym6_eig(H, lam, V);
+    for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(lam[i]));
+    const double thr = 6.0 * DBL_EPSILON * mx;
+    memset(x, 0, 6 * sizeof(double));
+    for (int i = 0; i < 6; ++i) {
+        if (!(fabs(lam[i]) > thr)) continue;
+        double d = 0.0;
+        for (int k = 0; k < 6; ++k) d += V[k * 6 + i] * b[k];
+        d /= lam[i];
+        for (int k = 0; k < 6; ++k) x[k] += d * V[k * 6 + i];
+    }
+}
+
+/* More-Thuente pieces, ndt.hpp */
+static double mt_psi(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+static double mt_dpsi(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+static int mt_update_interval(double* a_l, double* f_l, double* g_l, double* a_u, double* f_u, double* g_u, double a_t, double f_t, double g_t) {
+    if (f_t > *f_l) { *a_u = a_t; *f_u = f_t; *g_u = g_t; return 0; }                                           /* U1 / a */
+    if (g_t * (*a_l - a_t) > 0) { *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0; }                               /* U2 / b */
+    if (g_t * (*a_l - a_t) < 0) { *a_u = *a_l; *f_u = *f_l; *g_u = *g_l; *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0; }   /* U3 / c */
+    return 1;
+}
+static double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+    if (a_t == a_l && a_t == a_u) return a_t;
+    int cond;
+    if (a_t == a_l) cond = 4;
+    else if (f_t > f_l) cond = 1;
+    else if (g_t * g_l < 0) cond = 2;
+    else if (fabs(g_t) <= fabs(g_l)) cond = 3;
+    else cond = 4;
+    if (cond == 1) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        const double w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        if (fabs(a_c - a_l) < fabs(a_q - a_l)) return a_c;
+        return 0.5 * (a_q + a_c);
+    }
+    if (cond == 2) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        const double w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        if (fabs(a_c - a_t) >= fabs(a_s - a_t)) return a_c;
+        return a_s;
+    }
+    if (cond == 3) {
+        const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        const double w = sqrt(z * z - g_t * g_l);
+        const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+        if (a_t > a_l) return fmin(a_t + 0.66 * (a_u - a_t), a_n);
+        return fmax(a_t + 0.66 * (a_u - a_t), a_n);
+    }
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+    const double w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+typedef struct {
+    const ora_handle* h; const ndt_pcl_params* prm; double d1, d2;
+    double aj[8][3], ah[15][3];     /* angular_jacobian_ / angular_hessian_ members */
+    int evals; int64_t n_nb;
+} pcl_ctx;
+static double pcl_derivs(pcl_ctx* c, const double p[6], int with_hessian, double g[6], double H[36]) {
+    pcl_angle_jacobian(p, c->aj);
+    if (with_hessian) pcl_angle_hessian(p, c->prm->hessian_d1_as_pcl, c->ah);
+    ++c->evals;
+    return pcl_pass(c->h, c->d1, c->d2, p, c->aj, c->ah, 1, with_hessian, g, H, &c->n_nb);
+}
+
+static double pcl_step_length_mt(pcl_ctx* c, const double x[6], double dir[6], double step_init, double step_max, double step_min,
+                                 double* score, double g[6], double H[36], double x_out[6]) {
+    const double phi_0 = -*score;
+    double d_phi_0 = 0.0;
+    for (int k = 0; k < 6; ++k) d_phi_0 += g[k] * dir[k];
+    d_phi_0 = -d_phi_0;
+    if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) { memcpy(x_out, x, 6 * sizeof(double)); return 0; }
+        d_phi_0 *= -1;
+        for (int k = 0; k < 6; ++k) dir[k] *= -1;
+    }
+    const int max_step_iterations = 10;
+    int step_iterations = 0;
+    const double mu = 1.e-4, nu = 0.9;
+    double a_l = 0, a_u = 0;
+    double f_l = mt_psi(a_l, phi_0, phi_0, d_phi_0, mu), g_l = mt_dpsi(d_phi_0, d_phi_0, mu);
+    double f_u = mt_psi(a_u, phi_0, phi_0, d_phi_0, mu), g_u = mt_dpsi(d_phi_0, d_phi_0, mu);
+    int interval_converged = (step_max - step_min) < 0, open_interval = 1;
+    double a_t = step_init;
+    a_t = fmin(a_t, step_max);
+    a_t = fmax(a_t, step_min);
+    double x_t[6];
+    for (int k = 0; k < 6; ++k) x_t[k] = x[k] + dir[k] * a_t;
+    *score = pcl_derivs(c, x_t, 1, g, H);
+    double phi_t = -*score, d_phi_t = 0.0;
+    for (int k = 0; k < 6; ++k) d_phi_t += g[k] * dir[k];
+    d_phi_t = -d_phi_t;
+    double psi_t = mt_psi(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = mt_dpsi(d_phi_t, d_phi_0, mu);
+    while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        if (open_interval) a_t = mt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else a_t = mt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        a_t = fmin(a_t, step_max);
+        a_t = fmax(a_t, step_min);
+        for (int k = 0; k < 6; ++k) x_t[k] = x[k] + dir[k] * a_t;
+        *score = pcl_derivs(c, x_t, 0, g, H);
+        phi_t = -*score; d_phi_t = 0.0;
+        for (int k = 0; k < 6; ++k) d_phi_t += g[k] * dir[k];
+        d_phi_t = -d_phi_t;
+        psi_t = mt_psi(a_t, phi_t, phi_0, d_phi_0, mu);
+        d_psi_t = mt_dpsi(d_phi_t, d_phi_0, mu);
+        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+            open_interval = 0;
+            f_l += phi_0 - mu * d_phi_0 * a_l; g_l += mu * d_phi_0;
+            f_u += phi_0 - mu * d_phi_0 * a_u; g_u += mu * d_phi_0;
+        }
+        if (open_interval) interval_converged = mt_update_interval(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, psi_t, d_psi_t);
+        else interval_converged = mt_update_interval(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, phi_t, d_phi_t);
+        step_iterations++;
+    }
+    if (step_iterations) {       /* computeHessian: angular_jacobian_ of x_t, angular_hessian_ still of the first trial */
+        ++c->evals;
+        pcl_pass(c->h, c->d1, c->d2, x_t, c->aj, c->ah, 0, 1, NULL, H, NULL);
+    }
+    memcpy(x_out, x_t, sizeof x_t);
+    return a_t;
+}
+
+int ora_pcl_align(ora_handle* h, const ndt_pcl_params* prm, const double guess[16], ndt_pcl_result* out) {
+    memset(out, 0, sizeof *out);
+    if (!h->n_vox) return out->status = NDT_ERR_NO_TARGET;
+    if (!h->src) return out->status = NDT_ERR_NO_SOURCE;
+    pcl_ctx c;
+    memset(&c, 0, sizeof c);
+    c.h = h; c.prm = prm;
+    pcl_gauss(h->res_d, prm->outlier_ratio, &c.d1, &c.d2);
+    double p[6], g[6], H[36];
+    ora_pcl_vector_from_matrix(guess, p);
+    double score = pcl_derivs(&c, p, 1, g, H);
+    int converged = 0, iters = 0;
+    while (!converged) {
+        double ng[6], delta[6];
+        for (int k = 0; k < 6; ++k) ng[k] = -g[k];
+        pcl_svd_solve(H, ng, delta);
+        double dn = 0.0;
+        for (int k = 0; k < 6; ++k) dn += delta[k] * delta[k];
+        dn = sqrt(dn);
+        if (dn == 0 || isnan(dn)) { converged = dn == 0; break; }
+        for (int k = 0; k < 6; ++k) delta[k] /= dn;
+        double p_new[6];
+        dn = pcl_step_length_mt(&c, p, delta, dn, prm->step_size, h->cfg.eps / 2, &score, g, H, p_new);
+        for (int k = 0; k < 6; ++k) delta[k] *= dn;
+        double Rd[3][3], td[3];
+        pcl_rt_from_vector(delta, Rd, td);
+        for (int k = 0; k < 6; ++k) p[k] += delta[k];
+        const double cos_angle = 0.5 * ((Rd[0][0] + Rd[1][1] + Rd[2][2]) - 1.0);
+        const double tsq = (td[0] * td[0] + td[1] * td[1]) + td[2] * td[2];
+        ++iters;
+        const double te = h->cfg.eps, re = prm->rotation_eps;
+        if (iters >= h->cfg.max_iterations || ((te > 0 && tsq <= te) && (re > 0 && cos_angle >= re)) ||
+            ((te <= 0) && (re > 0 && cos_angle >= re)) || ((te > 0 && tsq <= te) && (re <= 0)))
+            converged = 1;
+        (void)p_new;
+    }
+    out->iterations = iters; out->converged = converged; out->evaluations = c.evals;
+    out->score = score; out->trans_probability = score / (double)h->n_src; out->n_neighbours = c.n_nb;
+    memcpy(out->p, p, sizeof p); memcpy(out->gradient, g, sizeof g); memcpy(out->hessian, H, sizeof H);
+    ora_pcl_matrix_from_vector(p, out->T);
+    out->status = NDT_OK;
+    return NDT_OK;
+}

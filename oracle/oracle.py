@@ -31,6 +31,32 @@ class Result(C.Structure):
     ]
 
 
+class PclParams(C.Structure):
+    _fields_ = [("outlier_ratio", C.c_double), ("step_size", C.c_double), ("rotation_eps", C.c_double),
+                ("hessian_d1_as_pcl", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PclResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("p", C.c_double * 6), ("score", C.c_double), ("trans_probability", C.c_double),
+                ("gradient", C.c_double * 6), ("hessian", C.c_double * 36), ("n_neighbours", C.c_int64),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("status", C.c_int32), ("evaluations", C.c_int32)]
+
+
+def pcl_params(**kw):
+    prm = PclParams(0.55, 0.1, 0.0, 1, 0)
+    for k, v in kw.items():
+        if not hasattr(prm, k):
+            raise AttributeError(k)
+        setattr(prm, k, v)
+    return prm
+
+
+def pcl_result_dict(r):
+    return dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), p=np.array(r.p), score=r.score,
+                trans_probability=r.trans_probability, g=np.array(r.gradient), H=np.array(r.hessian).reshape(6, 6),
+                n_neighbours=r.n_neighbours, iterations=r.iterations, converged=bool(r.converged), evaluations=r.evaluations)
+
+
 def default_config(**kw):
     cfg = Config(1.0, 35, 1e-2, 7, 6, 20.0, 10, 0, 0.01, 1, 0)
     for k, v in kw.items():
@@ -68,6 +94,10 @@ def _load():
     lib.ora_target_key.argtypes = [vp, vp, vp]
     lib.ora_source_key.argtypes = [vp, vp, vp]
     lib.ora_voxel_downsample.argtypes = [vp, sz, sz, C.c_float, vp, vp, sz, C.POINTER(sz)]
+    lib.ora_pcl_eval.argtypes = [vp, C.POINTER(PclParams), vp, vp, vp, vp, vp]
+    lib.ora_pcl_align.argtypes = [vp, C.POINTER(PclParams), vp, C.POINTER(PclResult)]
+    lib.ora_pcl_vector_from_matrix.argtypes = [vp, vp]
+    lib.ora_pcl_matrix_from_vector.argtypes = [vp, vp]
     lib.ora_pack_key.restype = C.c_int64
     lib.ora_pack_key.argtypes = [C.c_int32] * 3
     return lib
@@ -173,6 +203,21 @@ class Oracle:
             raise RuntimeError(f"ora_export_voxels rc={rc}")
         return dict(keys=keys, counts=cnt, mean=mean, cov=cov, info=info, valid=valid)
 
+    # --- PCL compatibility mode
+    def pcl_eval(self, p, hessian=True, **prm):
+        p = np.ascontiguousarray(p, np.float64); g = np.zeros(6); H = np.zeros((6, 6))
+        sc = C.c_double(); nb = C.c_int64(); pr = pcl_params(**prm)
+        rc = lib().ora_pcl_eval(self._h, C.byref(pr), p.ctypes.data, C.addressof(sc), g.ctypes.data,
+                                H.ctypes.data if hessian else None, C.addressof(nb))
+        if rc:
+            raise RuntimeError(f"ora_pcl_eval rc={rc}")
+        return dict(score=sc.value, g=g, H=H if hessian else None, n_neighbours=nb.value)
+
+    def pcl_align(self, guess, **prm):
+        t = _T(guess); r = PclResult(); pr = pcl_params(**prm)
+        lib().ora_pcl_align(self._h, C.byref(pr), t.ctypes.data, C.byref(r))
+        return pcl_result_dict(r)
+
     def target_key(self, p):
         p = np.asarray(p, np.float32); c = np.zeros(3, np.int32)
         ok = lib().ora_target_key(self._h, p.ctypes.data, c.ctypes.data)
@@ -194,3 +239,15 @@ def voxel_downsample(pts, leaf=0.5, T=None):
     if rc:
         raise RuntimeError(f"ora_voxel_downsample rc={rc}")
     return out[:no.value].copy()
+
+
+def pcl_vector_from_matrix(T):
+    t = _T(T); p = np.zeros(6)
+    lib().ora_pcl_vector_from_matrix(t.ctypes.data, p.ctypes.data)
+    return p
+
+
+def pcl_matrix_from_vector(p):
+    p = np.ascontiguousarray(p, np.float64); t = np.zeros(16)
+    lib().ora_pcl_matrix_from_vector(p.ctypes.data, t.ctypes.data)
+    return t.reshape(4, 4).T.copy()

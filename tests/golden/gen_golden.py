@@ -230,9 +230,136 @@ def gen_downsample():
     np.savez_compressed(os.path.join(HERE, "downsample.npz"), **out)
 
 
+# ------------------------------------------------------------------ (v) PCL compatibility mode (§8(f) N4)
+def pcl_vector_from_matrix(T):
+    """Eigen's eulerAngles(0,1,2) (first angle in [0, pi]) + translation -> [t, angles]."""
+    m = T[:3, :3]
+    r0 = np.arctan2(m[1, 2], m[2, 2])
+    c2 = np.hypot(m[0, 0], m[0, 1])
+    if r0 > 0:
+        r0 -= np.pi
+        r1 = np.arctan2(-m[0, 2], -c2)
+    else:
+        r1 = np.arctan2(-m[0, 2], c2)
+    s1, c1 = np.sin(r0), np.cos(r0)
+    r2 = np.arctan2(s1 * m[2, 0] - c1 * m[1, 0], c1 * m[1, 1] - s1 * m[2, 1])
+    return np.concatenate([T[:3, 3], -np.array([r0, r1, r2])])
+
+
+def rot_xyz(a):
+    cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def pcl_derivatives(vox, src32, p, res=1.0, outlier_ratio=0.55, d1_as_pcl=True, float32_transform=True):
+    """score, gradient, Hessian of pcl::NormalDistributionsTransform::computeDerivatives (SURVEY.md App. A.4-A.5):
+    radius search over the centroids of the valid voxels with a kd-tree, Magnusson eq. 6.9-6.13 and 6.17-6.21."""
+    from scipy.spatial import cKDTree
+    c1 = 10 * (1 - outlier_ratio); c2 = outlier_ratio / res ** 3; d3 = -np.log(c2)
+    d1 = -np.log(c1 + c2) - d3
+    d2 = -2 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / d1)
+    keys = [k for k, v in vox.items() if v[2]]
+    means = np.array([np.array(k, np.float64) * res + vox[k][0] for k in keys])
+    infos = np.array([vox[k][1] for k in keys])
+    R = rot_xyz(p[3:])
+    if float32_transform:
+        M = np.hstack([R, p[:3, None]]).astype(np.float32)
+        x32 = src32.astype(np.float32)
+        q = (((M[:, 0] * x32[:, :1] + M[:, 1] * x32[:, 1:2]) + M[:, 2] * x32[:, 2:3]) + M[:, 3]).astype(np.float64)
+        tree = cKDTree(means.astype(np.float32).astype(np.float64))
+    else:
+        q = src32.astype(np.float64) @ R.T + p[:3]
+        tree = cKDTree(means)
+    cs = [1.0 if abs(a) < 10e-5 else np.cos(a) for a in p[3:]]
+    sn = [0.0 if abs(a) < 10e-5 else np.sin(a) for a in p[3:]]
+    (cx, cy, cz), (sx, sy, sz) = cs, sn
+    aj = np.array([[-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy], [cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy],
+                   [-sy * cz, sy * sz, cy], [sx * cy * cz, -sx * cy * sz, sx * sy], [-cx * cy * cz, cx * cy * sz, -cx * sy],
+                   [-cy * sz, -cy * cz, 0], [cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0], [sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0]])
+    ah = np.array([[-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy], [-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy],
+                   [cx * cy * cz, -cx * cy * sz, cx * sy], [sx * cy * cz, -sx * cy * sz, sx * sy],
+                   [-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0], [cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0],
+                   [-cy * cz, cy * sz, sy if d1_as_pcl else -sy], [-sx * sy * cz, sx * sy * sz, sx * cy], [cx * sy * cz, -cx * sy * sz, -cx * cy],
+                   [sy * sz, sy * cz, 0], [-sx * cy * sz, -sx * cy * cz, 0], [cx * cy * sz, cx * cy * cz, 0],
+                   [-cy * cz, cy * sz, 0], [-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0], [-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0]])
+    score = 0.0; g = np.zeros(6); H = np.zeros((6, 6)); nb = 0; margin = np.inf
+    x64 = src32.astype(np.float64)
+    for i, idxs in enumerate(tree.query_ball_point(q, res)):
+        if not idxs:
+            continue
+        xa = aj @ x64[i]; xh = ah @ x64[i]
+        J = np.zeros((3, 6)); J[:, :3] = np.eye(3)
+        J[1, 3], J[2, 3], J[0, 4], J[1, 4], J[2, 4], J[0, 5], J[1, 5], J[2, 5] = xa
+        HE = np.zeros((6, 6, 3))
+        a, b, c = np.array([0, xh[0], xh[1]]), np.array([0, xh[2], xh[3]]), np.array([0, xh[4], xh[5]])
+        d, e, f = xh[6:9], xh[9:12], xh[12:15]
+        HE[3, 3], HE[4, 3], HE[5, 3] = a, b, c
+        HE[3, 4], HE[4, 4], HE[5, 4] = b, d, e
+        HE[3, 5], HE[4, 5], HE[5, 5] = c, e, f
+        for k in idxs:
+            dist = np.linalg.norm(q[i] - tree.data[k])
+            margin = min(margin, abs(dist - res))
+            nb += 1
+            xt = q[i] - means[k]
+            Ci = infos[k]
+            ex = np.exp(-d2 * (xt @ Ci @ xt) / 2)
+            w = d2 * ex
+            if w > 1 or w < 0 or np.isnan(w):
+                continue
+            score += -d1 * ex
+            w *= d1
+            xcJ = xt @ Ci @ J
+            g += xcJ * w
+            H += w * (-d2 * np.outer(xcJ, xcJ) + np.einsum("r,abr->ab", Ci @ xt, HE) + J.T @ Ci @ J)
+    return score, g, H, nb, margin
+
+
+def gen_pcl():
+    pair = np.load(os.path.join(HERE, "pair.npz"))
+    m, s, guess = pair["map"], pair["scan"], pair["guess"]
+    vox = build_map(m, quantize=True)
+    p = pcl_vector_from_matrix(guess)
+    assert np.allclose(rot_xyz(p[3:]), guess[:3, :3], atol=1e-12)
+    out = {"p": p, "guess": guess}
+    # formula check in float64 (no float32 rounding noise): analytic gradient / Hessian (eq. 6.21 sign) against central
+    # differences of the score / gradient.  Neighbour sets are frozen by the tiny step.
+    h = 1e-6
+    _, g0, H0, _, _ = pcl_derivatives(vox, s, p, d1_as_pcl=False, float32_transform=False)
+    gn = np.zeros(6); Hn = np.zeros((6, 6))
+    for k in range(6):
+        dp = np.zeros(6); dp[k] = h
+        sp, gp, _, _, _ = pcl_derivatives(vox, s, p + dp, d1_as_pcl=False, float32_transform=False)
+        sm, gm, _, _, _ = pcl_derivatives(vox, s, p - dp, d1_as_pcl=False, float32_transform=False)
+        gn[k] = (sp - sm) / (2 * h); Hn[:, k] = (gp - gm) / (2 * h)
+    assert np.allclose(gn, g0, rtol=1e-5, atol=1e-5 * np.abs(g0).max()), (gn, g0)
+    assert np.allclose(Hn, H0, rtol=1e-4, atol=1e-5 * np.abs(H0).max()), (Hn - H0)
+    for tag, flag in (("pcl", True), ("eq621", False)):
+        sc, g, H, nb, margin = pcl_derivatives(vox, s, p, d1_as_pcl=flag)
+        assert margin > 1e-5, margin       # no neighbour sits on the radius: float32 / float64 distance tests agree
+        out[f"score_{tag}"], out[f"g_{tag}"], out[f"H_{tag}"], out[f"nb_{tag}"] = sc, g, H, nb
+    # the same against float64 voxel payloads (no float32 rounding of the table: pins the oracle to 1e-9)
+    vox0 = build_map(m, quantize=False)
+    sc, g, H, nb, margin = pcl_derivatives(vox0, s, p, d1_as_pcl=True)
+    assert margin > 1e-5, margin
+    out["score_q0"], out["g_q0"], out["H_q0"], out["nb_q0"] = sc, g, H, nb
+    # a second transform vector with large angles (exercises every angular term)
+    p2 = p + np.array([0.3, -0.2, 0.1, 0.4, -0.3, 0.5])
+    sc, g, H, nb, margin = pcl_derivatives(vox, s, p2, d1_as_pcl=True)
+    assert margin > 1e-5, margin
+    out["p2"], out["score2"], out["g2"], out["H2"], out["nb2"] = p2, sc, g, H, nb
+    np.savez_compressed(os.path.join(HERE, "pcl.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pcl":
+        gen_pcl()
+        sys.exit(0)
     gen_downsample()
     gen_keys()
     gen_voxels()
     gen_pair()
+    gen_pcl()
     print("golden vectors written to", HERE)
