@@ -169,6 +169,37 @@ def main():
                                "kernel": f"k_residual<{a.nearby}>", "kernel_avg_us": k1, "points_per_launch": int(n1),
                                "hits_per_point": h1, "bytes_per_point": algorithmic_bytes_per_point(a.nearby, h1)}}
 
+    # ---- PCL compatibility mode: the objective / optimiser the reference's PCL build runs, on the
+    # same scan and map, with the reference's own parameters (process.cc:373-376: <= 35 iterations, eps 0.01, step 0.1)
+    pcl = None
+    if a.mode == "replay" and world == 1:
+        ndt_p = la.NDT(device=local, max_iterations=35, eps=0.01)
+        ndt_p.load_map(ndt.save_map()); ndt_p.set_source(w["scan"])
+        pvec = la.pcl_vector_from_matrix(w["guess"])
+        for _ in range(3):
+            rp = ndt_p.pcl_align(w["guess"])
+        repsp = max(20, a.steps); t0 = time.perf_counter()
+        for _ in range(repsp):
+            rp = ndt_p.pcl_align(w["guess"])
+        elp = time.perf_counter() - t0
+        usp, vxp, nbp = ndt_p.pcl_time_pass(pvec, hessian=True, reps=100)
+        bppp = 12 + 8 * 27 + 40 * vxp
+        achp = len(w["scan"]) * bppp / (usp * 1e-6) / 1e9
+        pcl = {"ms_per_align": 1e3 * elp / repsp, "iterations": rp["iterations"], "evaluations": rp["evaluations"],
+               "value": len(w["scan"]) * rp["evaluations"] * repsp / elp, "unit": "source-points*evaluations/s",
+               "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
+                            "kernel": "k_pcl_pass<hessian, gradient>", "kernel_avg_us": usp, "bytes_per_point": bppp,
+                            "voxels_met_per_point": vxp, "neighbours_per_point": nbp, "points_per_launch": int(len(w["scan"])),
+                            "algorithmic_bytes": "12 + 8*27 + 40*(valid voxels met in the 27 cells)"}}
+        if not a.no_cpu:
+            from oracle.oracle import Oracle
+            o = Oracle(max_iterations=35, eps=0.01); o.set_target(w["map"]); o.set_source(w["scan"])
+            t0 = time.perf_counter(); ro = o.pcl_align(w["guess"]); elo = time.perf_counter() - t0
+            pcl["cpu_baseline"] = {"value": len(w["scan"]) * ro["evaluations"] / elo, "unit": "source-points*evaluations/s", "cores": 1,
+                                   "kind": "port", "ms_per_align": 1e3 * elo,
+                                   "sample": f"1 align ({ro['evaluations']} evaluations) of the same scan, oracle's PCL-literal restatement"}
+        ndt_p.close()
+
     # ---- the timed workload
     if a.mode == "sharded":
         from lio_slam_amd.shard import shard_range
@@ -244,6 +275,7 @@ def main():
                      "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"},
         "final_pose_error_m_max": max(err) if err else None,
         "single_scan": single,
+        "pcl_mode": pcl,
     }
     if rank == 0 and world == 1 and not a.no_cpu:
         out.update(time_cpu_baseline(w, a.iters, a.nearby))

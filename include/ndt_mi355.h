@@ -225,6 +225,10 @@ int ndt_pcl_eval(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], do
                  int64_t* n_neighbours);
 /* computeTransformation from `guess` (column-major 4x4).  NDT_OK also when the iteration cap ended the loop. */
 int ndt_pcl_align(ndt_handle* h, const ndt_pcl_params* prm, const double guess[16], ndt_pcl_result* out);
+/* Measurement helper (bench.py): mean microseconds of the derivative pass alone at p, HIP events around `reps`
+ * back-to-back launches; valid voxels met in the 27 cells and neighbours accepted, per source point. */
+int ndt_pcl_time_pass(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], int with_hessian, int reps,
+                      double* us_per_launch, double* voxels_per_point, double* neighbours_per_point);
 /* Host helpers of the mode: p <-> matrix (Eigen's eulerAngles(0,1,2) convention, first angle in [0, pi]). */
 void ndt_pcl_vector_from_matrix(const double T[16], double p[6]);
 void ndt_pcl_matrix_from_vector(const double p[6], double T[16]);

@@ -41,6 +41,7 @@ class NormalDistributionsTransform {
 
     explicit NormalDistributionsTransform(int device = 0) {
         ndt_default_config(&cfg_);
+        ndt_pcl_default_params(&pcl_);
         cfg_.device = device;
     }
     ~NormalDistributionsTransform() { ndt_destroy(h_); }
@@ -51,7 +52,16 @@ class NormalDistributionsTransform {
     void setResolution(float r) { cfg_.resolution = r; reconfigure(); }
     void setMaximumIterations(int n) { cfg_.max_iterations = n; reconfigure(); }
     void setTransformationEpsilon(double e) { cfg_.eps = e; reconfigure(); }
-    void setStepSize(double) {}   // More-Thuente step cap of PCL's Newton NDT: Gauss-Newton has no line search
+    // More-Thuente step cap of PCL's Newton NDT: used in PCL compatibility mode; Gauss-Newton has no line search
+    void setStepSize(double s) { pcl_.step_size = s; }
+    // PCL compatibility mode (ndt_pcl_align): the objective, Newton step and More-Thuente line search of
+    // pcl::NormalDistributionsTransform, i.e. what the reference's build runs at process.cc:94.  Off by default:
+    // the engine's Gauss-Newton NEARBY7 form is the north-star path.
+    void setPclCompatibility(bool on) { pcl_mode_ = on; }
+    void setOulierRatio(double r) { pcl_.outlier_ratio = r; }     // (sic) PCL's spelling
+    void setOutlierRatio(double r) { pcl_.outlier_ratio = r; }
+    double getTransformationProbability() const { return pres_.trans_probability; }
+    const ndt_pcl_result& pclResult() const { return pres_; }
     // --- parameters PCL leaves at its defaults
     void setNearby(int k) { cfg_.nearby = k; reconfigure(); }
     void setMinPointsPerVoxel(int n) { cfg_.min_pts_in_voxel = n; reconfigure(); }
@@ -71,6 +81,17 @@ class NormalDistributionsTransform {
     // accepted and left untouched.  Errors do not throw here (PCL prints and clears converged_; the reference
     // ignores both, process.cc:94-95): status() tells.
     void align(const double* guess_colmajor) {
+        if (pcl_mode_) {
+            status_ = ndt_pcl_align(handle(), &pcl_, guess_colmajor, &pres_);
+            res_ = ndt_result{};
+            for (int i = 0; i < 16; ++i) res_.T[i] = pres_.T[i];
+            for (int i = 0; i < 36; ++i) res_.H[i] = -pres_.hessian[i];   // the score is maximised: -Hessian is the curvature
+            for (int i = 0; i < 6; ++i) res_.b[i] = pres_.gradient[i];    // (order [t, euler angles], not [rot, trans])
+            res_.iterations = pres_.iterations;
+            res_.converged = status_ == NDT_OK ? pres_.converged : 0;
+            res_.status = status_;
+            return;
+        }
         status_ = ndt_align(handle(), guess_colmajor, &res_);
         if (status_ != NDT_OK) res_.converged = 0;
     }
@@ -122,6 +143,9 @@ class NormalDistributionsTransform {
     void check(int rc) { if (rc != NDT_OK) throw Error(rc, ndt_last_error(h_)); }
 
     ndt_config cfg_{};
+    ndt_pcl_params pcl_{};
+    ndt_pcl_result pres_{};
+    bool pcl_mode_ = false;
     ndt_handle* h_ = nullptr;
     ndt_result res_{};
     int status_ = NDT_OK;

@@ -23,7 +23,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
-    "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
+    "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
 ]
@@ -105,6 +105,7 @@ def lib():
     L.ndt_pcl_default_params.argtypes = [C.POINTER(PclParams)]
     L.ndt_pcl_eval.argtypes = [vp, C.POINTER(PclParams), vp, vp, vp, vp, vp]
     L.ndt_pcl_align.argtypes = [vp, C.POINTER(PclParams), vp, C.POINTER(PclResult)]
+    L.ndt_pcl_time_pass.argtypes = [vp, C.POINTER(PclParams), vp, C.c_int, C.c_int, vp, vp, vp]
     L.ndt_pcl_vector_from_matrix.argtypes = [vp, vp]
     L.ndt_pcl_matrix_from_vector.argtypes = [vp, vp]
     L.ndt_map_save.argtypes = [vp, vp, sz, C.POINTER(sz)]
@@ -326,6 +327,13 @@ class NDT:
         return dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), p=np.array(r.p), score=r.score,
                     trans_probability=r.trans_probability, g=np.array(r.gradient), H=np.array(r.hessian).reshape(6, 6),
                     n_neighbours=r.n_neighbours, iterations=r.iterations, converged=bool(r.converged), evaluations=r.evaluations)
+
+    def pcl_time_pass(self, p, hessian=True, reps=50, **prm):
+        """(us per launch, valid voxels met per point, neighbours per point) of the PCL-mode derivative pass."""
+        p = np.ascontiguousarray(p, np.float64); pr = self.pcl_params(**prm)
+        us = C.c_double(); vx = C.c_double(); nb = C.c_double()
+        self._chk(lib().ndt_pcl_time_pass(self._h, C.byref(pr), p.ctypes.data, int(hessian), int(reps), C.addressof(us), C.addressof(vx), C.addressof(nb)))
+        return us.value, vx.value, nb.value
 
     def save_map(self):
         """The resident voxel map as bytes (layout: include/ndt_mi355.h, ndt_map_save)."""

@@ -553,6 +553,15 @@ int ndt_pcl_eval(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], do
     return pcl_eval(e, *prm, p, score, g, H, n_neighbours, h->err);
 }
 
+int ndt_pcl_time_pass(ndt_handle* h, const ndt_pcl_params* prm, const double p[6], int with_hessian, int reps, double* us_per_launch,
+                      double* voxels_per_point, double* neighbours_per_point) {
+    if (!h || !p || reps < 1) return NDT_ERR_INVALID_ARG;
+    PclEngine e;
+    int rc = pcl_engine(h, prm, &e);
+    if (rc != NDT_OK) return rc;
+    return pcl_time_pass(e, *prm, p, with_hessian != 0, reps, us_per_launch, voxels_per_point, neighbours_per_point, h->err);
+}
+
 int ndt_pcl_align(ndt_handle* h, const ndt_pcl_params* prm, const double guess[16], ndt_pcl_result* out) {
     if (!h || !guess || !out) return NDT_ERR_INVALID_ARG;
     PclEngine e;

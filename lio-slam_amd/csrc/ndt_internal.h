@@ -96,6 +96,8 @@ int pcl_grid(size_t n);
 void pcl_matrix_from_vector(const double p[6], double T[16]);
 void pcl_vector_from_matrix(const double T[16], double p[6]);
 int pcl_eval(const PclEngine& e, const ndt_pcl_params& prm, const double p[6], double* score, double g[6], double* H, int64_t* n_nb, std::string& err);
+int pcl_time_pass(const PclEngine& e, const ndt_pcl_params& prm, const double p[6], bool with_hessian, int reps, double* us_per_launch,
+                  double* voxels_per_point, double* neighbours_per_point, std::string& err);
 int pcl_align(const PclEngine& e, const ndt_pcl_params& prm, int max_iterations, double trans_eps, const double guess[16], ndt_pcl_result* out,
               std::string& err);
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);

@@ -27,6 +27,7 @@
 #define PCL_ACC_G 21
 #define PCL_ACC_SCORE 27
 #define PCL_ACC_NB 28
+#define PCL_ACC_VOX 29      // valid voxels met in the 27 cells (for the algorithmic byte count)
 
 struct PclPass {
     float M[12];          // row-major 3x4, float32 like PCL's final_transformation_
@@ -37,19 +38,19 @@ struct PclPass {
     float r2f;            // (float)(resolution^2)
 };
 
-// nine cells (dy, dx in -1..1) of the plane dz: keys, resolve, payloads, neighbour sums
-__device__ __forceinline__ void pcl_plane(const PclPass& pp, const float* qf, const int32_t* c, int dz, const int64_t* __restrict__ keys,
+// three cells (dx in -1..1) of the row (dy, dz): keys, resolve, payloads, neighbour sums.  Three probes at a time keep
+// the kernel at two waves per SIMD; nine at a time need 386 registers.
+__device__ __forceinline__ void pcl_row(const PclPass& pp, const float* qf, const int32_t* c, int dy, int dz, const int64_t* __restrict__ keys,
                                           const VoxSlot* __restrict__ slots, uint32_t mask, bool point_ok, double* G, double* S, double* Mm,
-                                          double& score, double& nb) {
-    int64_t want[9];
-    uint32_t s0[9];
-    Key2 ka[9], kb[9];
-    bool live[9];
-    const int32_t n2 = c[2] + dz;
+                                          double& score, double& nb, double& nvox) {
+    int64_t want[3];
+    uint32_t s0[3];
+    Key2 ka[3], kb[3];
+    bool live[3];
+    const int32_t n1 = c[1] + dy, n2 = c[2] + dz;
 #pragma unroll
-    for (int pr = 0; pr < 9; ++pr) {
-        const int dy = pr / 3 - 1, dx = pr % 3 - 1;
-        const int32_t n0 = c[0] + dx, n1 = c[1] + dy;
+    for (int pr = 0; pr < 3; ++pr) {
+        const int32_t n0 = c[0] + pr - 1;
         live[pr] = point_ok && cell_ok(n0) && cell_ok(n1) && cell_ok(n2);
         want[pr] = ndt_pack(n0, n1, n2);
         s0[pr] = live[pr] ? ndt_hash_cell(n0, n1, n2) & mask : 0u;
@@ -57,10 +58,10 @@ __device__ __forceinline__ void pcl_plane(const PclPass& pp, const float* qf, co
         ka[pr] = kp[0];
         kb[pr] = kp[1];
     }
-    uint32_t fs[9], cur[9];
+    uint32_t fs[3], cur[3];
     unsigned pending = 0;
 #pragma unroll
-    for (int pr = 0; pr < 9; ++pr) {
+    for (int pr = 0; pr < 3; ++pr) {
         const int64_t w = want[pr];
         const bool m0 = ka[pr].x == w, m1 = ka[pr].y == w, m2 = kb[pr].x == w, m3 = kb[pr].y == w;
         const bool e0 = ka[pr].x == NDT_KEY_EMPTY, e1 = ka[pr].y == NDT_KEY_EMPTY, e2 = kb[pr].x == NDT_KEY_EMPTY, e3 = kb[pr].y == NDT_KEY_EMPTY;
@@ -72,11 +73,11 @@ __device__ __forceinline__ void pcl_plane(const PclPass& pp, const float* qf, co
         cur[pr] = (s0[pr] + 4) & mask;
     }
     while (__any(pending != 0)) {      // chains longer than four entries (rare): all probes advance together
-        int64_t kx[9];
+        int64_t kx[3];
 #pragma unroll
-        for (int pr = 0; pr < 9; ++pr) kx[pr] = keys[cur[pr]];
+        for (int pr = 0; pr < 3; ++pr) kx[pr] = keys[cur[pr]];
 #pragma unroll
-        for (int pr = 0; pr < 9; ++pr) {
+        for (int pr = 0; pr < 3; ++pr) {
             const bool pend = (pending >> pr) & 1u;
             const bool hit = pend && kx[pr] == want[pr], stop = pend && (hit || kx[pr] == NDT_KEY_EMPTY);
             fs[pr] = hit ? cur[pr] : fs[pr];
@@ -84,14 +85,13 @@ __device__ __forceinline__ void pcl_plane(const PclPass& pp, const float* qf, co
             cur[pr] = (pend && !stop) ? (cur[pr] + 1) & mask : cur[pr];
         }
     }
-    Payload pay[9];
+    Payload pay[3];
 #pragma unroll
-    for (int pr = 0; pr < 9; ++pr) pay[pr] = load_payload(slots, fs[pr]);
+    for (int pr = 0; pr < 3; ++pr) pay[pr] = load_payload(slots, fs[pr]);
     const double res = pp.kp.res_d;
 #pragma unroll
-    for (int pr = 0; pr < 9; ++pr) {
-        const int dy = pr / 3 - 1, dx = pr % 3 - 1;
-        const int32_t n0 = c[0] + dx, n1 = c[1] + dy;
+    for (int pr = 0; pr < 3; ++pr) {
+        const int32_t n0 = c[0] + pr - 1;
         const bool vox = fs[pr] != SLOT_NONE && pay[pr].a.x != 0;
         const float o0 = __int_as_float(pay[pr].a.z), o1 = __int_as_float(pay[pr].a.w), o2 = pay[pr].b.x;
         const double i22 = __int_as_float(pay[pr].a.y), i00 = pay[pr].b.y, i01 = pay[pr].b.z, i02 = pay[pr].b.w, i11 = pay[pr].c.x, i12 = pay[pr].c.y;
@@ -112,6 +112,7 @@ __device__ __forceinline__ void pcl_plane(const PclPass& pp, const float* qf, co
         const bool ok = nbr && !(e > 1.0 || e < 0.0 || e != e);         // updateDerivatives' validity test
         const double w = ok ? pp.d1 * e : 0.0;
         nb += nbr ? 1.0 : 0.0;
+        nvox += vox ? 1.0 : 0.0;
         score += ok ? -pp.d1 * ex : 0.0;
         // selects, not multiplies by zero: the stand-in payload of a miss may give inf / NaN above
         const double a0 = ok ? g0 : 0.0, a1 = ok ? g1 : 0.0, a2 = ok ? g2 : 0.0;
@@ -144,10 +145,11 @@ __global__ __launch_bounds__(PCL_THREADS) void k_pcl_pass(const float* __restric
         bool ok = i < n && isfinite(qf[0]) && isfinite(qf[1]) && isfinite(qf[2]);
         ok = ok && ndt_target_cell(pp.kp, qf[0], qf[1], qf[2], c);
         if (!ok) { c[0] = c[1] = c[2] = 0; qf[0] = qf[1] = qf[2] = 0.f; x = y = z = 0.f; }   // nothing non-finite may reach the sums
-        double G[3] = {0, 0, 0}, S[6] = {0, 0, 0, 0, 0, 0}, Mm[6] = {0, 0, 0, 0, 0, 0}, score = 0.0, nb = 0.0;
+        double G[3] = {0, 0, 0}, S[6] = {0, 0, 0, 0, 0, 0}, Mm[6] = {0, 0, 0, 0, 0, 0}, score = 0.0, nb = 0.0, nvox = 0.0;
 #pragma unroll 1
-        for (int dz = -1; dz <= 1; ++dz) pcl_plane(pp, qf, c, dz, keys, slots, mask, ok, G, S, Mm, score, nb);
+        for (int row = 0; row < 9; ++row) pcl_row(pp, qf, c, row % 3 - 1, row / 3 - 1, keys, slots, mask, ok, G, S, Mm, score, nb, nvox);
         acc[PCL_ACC_NB] += nb;
+        acc[PCL_ACC_VOX] += nvox;
         if (!__any(nb != 0.0)) continue;
         if (GRAD) acc[PCL_ACC_SCORE] += score;
         // point Jacobian (computePointDerivatives): columns 3..5 of J_E from the ORIGINAL point
@@ -540,5 +542,43 @@ int pcl_align(const PclEngine& e, const ndt_pcl_params& prm, int max_iterations,
     std::memcpy(out->p, p, sizeof p); std::memcpy(out->gradient, g, sizeof g); std::memcpy(out->hessian, H, sizeof H);
     pcl_matrix_from_vector(p, out->T);
     out->status = NDT_OK;
+    return NDT_OK;
+}
+
+// Measurement: mean duration of the derivative pass alone (HIP events on the engine's stream around `reps`
+// back-to-back launches), and what it met per source point.
+int pcl_time_pass(const PclEngine& e, const ndt_pcl_params& prm, const double p[6], bool with_hessian, int reps, double* us_per_launch,
+                  double* voxels_per_point, double* neighbours_per_point, std::string& err) {
+    Driver d;
+    d.e = &e; d.prm = &prm; d.err = &err;
+    gauss_constants(e.kp.res_d, prm.outlier_ratio, &d.d1, &d.d2);
+    double sc, g[6], H[36];
+    int rc = d.derivs(p, with_hessian, &sc, g, H);       // warm-up + the per-point counts
+    if (rc != NDT_OK) return rc;
+    if (voxels_per_point) *voxels_per_point = e.n ? e.h_row[PCL_ACC_VOX] / (double)e.n : 0.0;
+    if (neighbours_per_point) *neighbours_per_point = e.n ? e.h_row[PCL_ACC_NB] / (double)e.n : 0.0;
+    PclPass pp;
+    double R[3][3], t[3];
+    rt_from_vector(p, R, t);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) pp.M[4 * r + c] = (float)R[r][c]; pp.M[4 * r + 3] = (float)t[r]; }
+    std::memcpy(pp.aj, d.aj, sizeof d.aj); std::memcpy(pp.ah, d.ah, sizeof d.ah);
+    pp.d1 = d.d1; pp.d2 = d.d2; pp.kp = e.kp; pp.r2f = (float)(e.kp.res_d * e.kp.res_d);
+    hipEvent_t a, b;
+    hipError_t hr = hipEventCreate(&a);
+    if (hr == hipSuccess) hr = hipEventCreate(&b);
+    if (hr != hipSuccess) { err = hipGetErrorString(hr); return NDT_ERR_HIP; }
+    const int grid = pcl_grid(e.n);
+    hipEventRecord(a, e.stream);
+    for (int i = 0; i < reps; ++i) {
+        if (with_hessian) k_pcl_pass<true, true><<<grid, PCL_THREADS, 0, e.stream>>>(e.sx, e.sy, e.sz, (int64_t)e.n, e.keys, e.slots, e.mask, pp, e.partials);
+        else k_pcl_pass<false, true><<<grid, PCL_THREADS, 0, e.stream>>>(e.sx, e.sy, e.sz, (int64_t)e.n, e.keys, e.slots, e.mask, pp, e.partials);
+    }
+    hipEventRecord(b, e.stream);
+    hr = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (hr == hipSuccess) hr = hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    if (hr != hipSuccess) { err = hipGetErrorString(hr); return NDT_ERR_HIP; }
+    if (us_per_launch) *us_per_launch = 1000.0 * (double)ms / (double)reps;
     return NDT_OK;
 }

@@ -56,5 +56,13 @@ int main(int argc, char** argv) {
     printf("\n");
     for (double v : H) printf("%.17g ", v);
     printf("\n");
+    // the same call sequence in PCL compatibility mode (what the reference's PCL build computes at process.cc:94)
+    ndt_.setPclCompatibility(true);
+    ndt_.align(output, guess);
+    auto Tp = ndt_.getFinalTransformation();
+    printf("status %d converged %d iterations %d probability %.17g\n", ndt_.status(), (int)ndt_.hasConverged(), ndt_.getFinalNumIteration(),
+           ndt_.getTransformationProbability());
+    for (double v : Tp) printf("%.17g ", v);
+    printf("\n");
     return 0;
 }

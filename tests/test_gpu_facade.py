@@ -38,3 +38,12 @@ def test_cpp_facade_matches_oracle(tmp_path):
     dt, dr = pose_error(T, r["T"])
     assert dt < 1e-4 and dr < 1e-5
     assert rel_err(H, r["H"]) < 1e-5
+    # PCL compatibility mode through the same facade calls
+    st2 = lines[3].split()
+    Tp = np.array(lines[4].split(), float).reshape(4, 4).T
+    o.set_params(max_iterations=35, eps=0.01)
+    rp = o.pcl_align(guess32.astype(np.float64), step_size=0.1)
+    assert int(st2[1]) == 0 and int(st2[3]) == int(rp["converged"]) and int(st2[5]) == rp["iterations"]
+    assert abs(float(st2[7]) - rp["trans_probability"]) <= 1e-6 * abs(rp["trans_probability"])
+    dt, dr = pose_error(Tp, rp["T"])
+    assert dt < 1e-6 and dr < 1e-7
