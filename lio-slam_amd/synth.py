@@ -206,3 +206,52 @@ def make_config(index, small=False):
         raise ValueError("configs 3 and 4 are assembled by bench.py from these pieces")
     guess = T_true @ perturbation(rng)
     return dict(map=m, scan=s, T_true=T_true, guess=guess, scene=scene, poses=poses, rng=rng)
+
+
+# ------------------------------------------------------------------ IMU + LiDAR streams
+GRAVITY = np.array([0.0, 0.0, -9.81])      # world gravity; a level IMU at rest measures +9.81 on z
+
+
+class Motion:
+    """Body (IMU) pose over time: at rest until t_move, then a smooth drive with gentle yaw / roll / pitch.
+    The world frame is the body frame at rest (the pipeline's map frame, process.cc:75-85)."""
+
+    def __init__(self, t_move=1.5, accel=0.6, v_max=1.2, yaw_amp=0.25, yaw_rate=0.35, tilt=0.02):
+        self.t_move, self.accel, self.v_max, self.yaw_amp, self.yaw_rate, self.tilt = t_move, accel, v_max, yaw_amp, yaw_rate, tilt
+
+    def _s(self, tau):     # distance driven: constant acceleration up to v_max, then constant speed
+        t1 = self.v_max / self.accel
+        return np.where(tau < t1, 0.5 * self.accel * tau ** 2, 0.5 * self.accel * t1 ** 2 + self.v_max * (tau - t1))
+
+    def pose(self, t):
+        tau = max(0.0, t - self.t_move)
+        s = float(self._s(np.float64(tau)))
+        yaw = self.yaw_amp * (1 - np.cos(self.yaw_rate * tau)) * 0.5
+        ramp = tau * tau / (1.0 + tau * tau)          # smooth start: no velocity step anywhere
+        roll = self.tilt * np.sin(0.9 * tau) * ramp; pitch = self.tilt * np.sin(0.7 * tau) * ramp
+        p = np.array([s * np.cos(0.15 * np.sin(0.2 * tau)), 0.6 * (1 - np.cos(0.25 * tau)), 0.01 * np.sin(0.5 * tau) * ramp])
+        Rz = se3([0, 0, yaw], [0, 0, 0])[:3, :3]; Ry = se3([0, pitch, 0], [0, 0, 0])[:3, :3]; Rx = se3([roll, 0, 0], [0, 0, 0])[:3, :3]
+        T = np.eye(4); T[:3, :3] = Rz @ Ry @ Rx; T[:3, 3] = p
+        return T
+
+
+def _log_so3(R):
+    c = min(1.0, max(-1.0, (np.trace(R) - 1) / 2)); th = np.arccos(c)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return 0.5 * w if th < 1e-9 else th / (2 * np.sin(th)) * w
+
+
+def imu_stream(motion, t0, t1, rate, rng, bg=(0, 0, 0), ba=(0, 0, 0), gyro_sigma=1e-3, acce_sigma=1e-2):
+    """(t, gyro[3], acce[3]) rows at `rate` Hz: body angular rate and specific force R^T (a - g) by central differences
+    of the analytic motion, plus constant biases and white noise."""
+    h = 1e-4
+    ts = t0 + np.arange(int(round((t1 - t0) * rate)) + 1) / rate
+    out = np.zeros((len(ts), 7))
+    for i, t in enumerate(ts):
+        Tm, T0, Tp = motion.pose(t - h), motion.pose(t), motion.pose(t + h)
+        w = _log_so3(Tm[:3, :3].T @ Tp[:3, :3]) / (2 * h)          # body frame (to first order around t)
+        a = (Tp[:3, 3] - 2 * T0[:3, 3] + Tm[:3, 3]) / (h * h)
+        out[i, 0] = t
+        out[i, 1:4] = w + np.asarray(bg) + rng.normal(0, gyro_sigma, 3)
+        out[i, 4:7] = T0[:3, :3].T @ (a - GRAVITY) + np.asarray(ba) + rng.normal(0, acce_sigma, 3)
+    return out
