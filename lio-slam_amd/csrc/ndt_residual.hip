@@ -37,10 +37,11 @@ __device__ __forceinline__ unsigned gate_and_sum(const Payload* pay, const uint3
         const double e0 = (q[0] - (double)(c[0] + dx) * ep.kp.res_d) - (double)__int_as_float(pay[pr].a.z);
         const double e1 = (q[1] - (double)(c[1] + dy) * ep.kp.res_d) - (double)__int_as_float(pay[pr].a.w);
         const double e2 = (q[2] - (double)(c[2] + dz) * ep.kp.res_d) - (double)pay[pr].b.x;
-        const double g0 = (i00 * e0 + i01 * e1) + i02 * e2;
-        const double g1 = (i01 * e0 + i11 * e1) + i12 * e2;
-        const double g2 = (i02 * e0 + i12 * e1) + i22 * e2;
-        const double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
+        // fused multiply-adds in this fixed order on both sides (oracle: C fma()): same bits, 8 instructions fewer per voxel
+        const double g0 = fma(i02, e2, fma(i01, e1, i00 * e0));
+        const double g1 = fma(i12, e2, fma(i11, e1, i01 * e0));
+        const double g2 = fma(i22, e2, fma(i12, e1, i02 * e0));
+        const double chi2 = fma(e2, g2, fma(e1, g1, e0 * g0));
         const bool ok = vox && chi2 <= ep.outlier_th;               // false for NaN
         hitmask |= ok ? 1u << pr : 0u;
         // w is exactly 0 or 1 and every operand is finite (payloads of valid voxels are finite, slot 0 stands in for

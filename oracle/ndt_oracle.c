@@ -35,6 +35,7 @@
  *   source key  = floor(q' * (double)inv_leaf_f32)          (FLOOR) or round() (ROUND)
  *   target key  = floorf(x_f32 * inv_leaf_f32)              (FLOOR) or round((double)x * inv)
  *   keyframe pt = (float)q'                                  then keyed as a target point
+ *   Sigma^-1 e  = fma(I2, e2, fma(I1, e1, I0*e0)) per row, chi2 = fma(e2, g2, fma(e1, g1, e0*g0))   (the gate is bit-exact)
  * The voxel table holds, per voxel, what the engine's residual kernel reads:
  * mean as a float32 offset from the voxel origin key*res, and the six unique
  * entries of the regularised inverse covariance as float32 (SURVEY.md §8(d):
@@ -438,10 +439,10 @@ static void eval_range(const ora_handle* h, const double R[3][3], const double t
             double e1 = (q[1] - (double)n1 * h->res_d) - v->pay_off[1];
             double e2 = (q[2] - (double)n2 * h->res_d) - v->pay_off[2];
             const double* I = v->pay_info;
-            double g0 = (I[0] * e0 + I[1] * e1) + I[2] * e2;
-            double g1 = (I[1] * e0 + I[3] * e1) + I[4] * e2;
-            double g2 = (I[2] * e0 + I[4] * e1) + I[5] * e2;
-            double chi2 = (e0 * g0 + e1 * g1) + e2 * g2;
+            double g0 = fma(I[2], e2, fma(I[1], e1, I[0] * e0));
+            double g1 = fma(I[4], e2, fma(I[3], e1, I[1] * e0));
+            double g2 = fma(I[5], e2, fma(I[4], e1, I[2] * e0));
+            double chi2 = fma(e2, g2, fma(e1, g1, e0 * g0));
             if (isnan(chi2) || chi2 > th) continue;
             mask |= (uint8_t)(1u << pr);
             for (int j = 0; j < 6; ++j) S[j] += I[j];
