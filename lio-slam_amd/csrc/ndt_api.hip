@@ -207,11 +207,14 @@ int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t 
     kp.inv_leaf_f32 = 1.0f / leaf; kp.inv_res_d = (double)kp.inv_leaf_f32; kp.res_d = (double)leaf; kp.key_rule = NDT_KEY_FLOOR_F32;
     double R[9], t[3];
     if (T) { for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; } }
-    size_t n_out = 0;
-    int rc = downsample_points(h->work, kp, pts, n, stride, T ? R : nullptr, T ? t : nullptr, h->sx, h->sy, h->sz, &n_out, h->stream, h->err);
+    const uint32_t* d_n_out = nullptr;
+    int rc = downsample_points(h->work, kp, pts, n, stride, T ? R : nullptr, T ? t : nullptr, h->sx, h->sy, h->sz, &d_n_out, h->stream, h->err);
     if (rc != NDT_OK) return rc;
+    uint32_t n32 = 0;
+    if (d_n_out) H_TRY(hipMemcpyAsync(&n32, d_n_out, 4, hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipStreamSynchronize(h->stream));        // the only wait after the bounding box: the caller's buffer is free, n is known
+    const size_t n_out = n32;
     H_TRY(h->partials.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
-    H_TRY(hipStreamSynchronize(h->stream));
     h->n_src = n_out;
     h->have_source = true;
     return NDT_OK;

@@ -44,7 +44,9 @@ struct SortKeyMap {        // packed key <-> compact radix-sort key for one batc
 };
 struct SortedCells {       // result of sort_points_by_cell
     size_t n_valid = 0;
-    uint32_t nseg = 0;
+    uint32_t nseg = 0;              // 0 when the count was left on the device (d_nseg)
+    const uint32_t* d_nseg = nullptr;
+    uint64_t bbox_cells = 0;        // cells in the bounding box (an upper bound of nseg known without a read-back)
     SortKeyMap km = {};
     int passes = 0;
     const uint64_t* sorted_keys = nullptr;
@@ -72,8 +74,10 @@ struct MapWork {
 // radix passes executed through *passes.
 int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
                      size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err);
+// Queues the work and leaves the number of centroids on the device (*d_n_out; nullptr if the cloud was empty): the
+// caller reads it back with its own final synchronisation instead of a second one in the middle.
 int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, size_t n, size_t stride, const double* R, const double* t,
-                      DevBuf& ox, DevBuf& oy, DevBuf& oz, size_t* n_out, hipStream_t s, std::string& err);
+                      DevBuf& ox, DevBuf& oy, DevBuf& oz, const uint32_t** d_n_out, hipStream_t s, std::string& err);
 int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& keys, std::vector<int32_t>& counts,
                std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
                std::vector<uint8_t>& valid, hipStream_t s, std::string& err);

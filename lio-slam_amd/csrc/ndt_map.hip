@@ -237,10 +237,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const uint32_t* in, 
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) { if (base + j < n) out[base + j] = ex; ex += v[j]; }
 }
+// small arrays (the radix histograms of a LiDAR scan): the whole exclusive scan in ONE block, one launch instead of three
+#define SCAN1_THREADS 1024
+#define SCAN1_ITEMS 8
+#define SCAN1_MAX (SCAN1_THREADS * SCAN1_ITEMS)    // one tile: beyond that a single CU's strided reads cost more than two extra launches
+__global__ __launch_bounds__(SCAN1_THREADS) void k_scan_single(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total) {
+    __shared__ uint32_t wsum[SCAN1_THREADS / 64];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (size_t base = 0; base < n; base += (size_t)SCAN1_THREADS * SCAN1_ITEMS) {
+        const size_t i0 = base + (size_t)threadIdx.x * SCAN1_ITEMS;
+        uint32_t v[SCAN1_ITEMS], sum = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN1_ITEMS; ++j) { v[j] = i0 + j < n ? in[i0 + j] : 0; sum += v[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tile = 0;
+        for (int j = 0; j < SCAN1_THREADS / 64; ++j) { const uint32_t x = wsum[j]; if (j < w) wbase += x; tile += x; }
+        uint32_t ex = carry_s + wbase + inc - sum;
+#pragma unroll
+        for (int j = 0; j < SCAN1_ITEMS; ++j) { if (i0 + j < n) out[i0 + j] = ex; ex += v[j]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tile;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
 // out may alias in.  tmp needs ceil(n / SCAN_TILE) + 1 uint32.
 static void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, uint32_t* total, hipStream_t s) {
     size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (!nb) { if (total) (void)hipMemsetAsync(total, 0, 4, s); return; }
+    if (n <= SCAN1_MAX) { k_scan_single<<<1, SCAN1_THREADS, 0, s>>>(in, out, n, total); return; }
     k_scan_reduce<<<(unsigned)nb, SCAN_THREADS, 0, s>>>(in, n, tmp);
     k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(tmp, nb, total);
     k_scan_down<<<(unsigned)nb, SCAN_THREADS, 0, s>>>(in, out, n, tmp);
@@ -249,15 +282,17 @@ static void exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint
 // ------------------------------------------------------------------ LSD radix sort, 8-bit digits, (u64 key, u32 value)
 
 #define RS_THREADS 256
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)
+// elements per thread: 16 for big clouds; 4 for a LiDAR scan, so that ~100k points still spread over > 100 blocks
+#define RS_ITEMS_BIG 16
+#define RS_ITEMS_SMALL 4
 
 // hist layout: digit-major, hist[d * nblk + blk], so one exclusive scan yields every (digit, block) base
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t* keys, size_t n, int shift, uint32_t* hist, unsigned nblk) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * RS_TILE;
+    size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
 #pragma unroll 4
     for (int r = 0; r < RS_ITEMS; ++r) {
         size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
@@ -268,13 +303,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t* keys,
 }
 
 // stable scatter: element order inside a tile is (round, wave, lane) = input order
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t* keys, const uint32_t* vals, size_t n, int shift,
                                                               const uint32_t* offs, unsigned nblk, uint64_t* okeys, uint32_t* ovals) {
     __shared__ uint32_t running[256];
     __shared__ uint32_t wcnt[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     running[threadIdx.x] = offs[(size_t)threadIdx.x * nblk + blockIdx.x];
-    size_t base = (size_t)blockIdx.x * RS_TILE;
+    size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
     for (int r = 0; r < RS_ITEMS; ++r) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
@@ -486,8 +522,9 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
 // pcl::VoxelGrid centroid (src/slam/src/process.cc:68-73): mean of the cell's points, float64 sum in sorted order,
 // one rounding to float32; output row = segment index (cells in PCL's index order when sorted z,y,x)
 template <int SEG_LANES>
-__global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_start, uint32_t nseg, const float* gx, const float* gy,
+__global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_start, const uint32_t* d_nseg, const float* gx, const float* gy,
                                                           const float* gz, float* ox, float* oy, float* oz) {
+    const uint32_t nseg = *d_nseg;      // the launch covers the upper bound n_valid; groups past nseg have nothing to do
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     uint32_t s = 0, e = 0;
@@ -666,7 +703,7 @@ static int finish_entries(VoxelMap& m, MapWork& w, const uint64_t* sorted_keys, 
 // segments (= cells) and the points gathered into sorted order (w.gx/gy/gz).  pts: AoS records in host or device
 // memory, or (stride == 0) three device SoA arrays passed through pts / soa_y / soa_z.
 int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
-                        const double* R, const double* t, bool zyx_order, hipStream_t s, SortedCells* out, std::string& err) {
+                        const double* R, const double* t, bool zyx_order, bool host_nseg, hipStream_t s, SortedCells* out, std::string& err) {
     *out = SortedCells();
     if (n == 0) return NDT_OK;
     if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
@@ -714,16 +751,20 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
 
     // LSD radix sort over the bits that exist
     const int P = std::max(1, (total_bits + 7) / 8);
-    const unsigned nblk = (unsigned)((n + RS_TILE - 1) / RS_TILE);
+    const bool big = n >= (1u << 20);
+    const size_t rs_tile = (size_t)RS_THREADS * (big ? RS_ITEMS_BIG : RS_ITEMS_SMALL);
+    const unsigned nblk = (unsigned)((n + rs_tile - 1) / rs_tile);
     const size_t nh = (size_t)256 * nblk;
     HIP_TRY(w.hist.ensure(nh * 4));
     HIP_TRY(w.scan_tmp.ensure(((std::max(nh, n) + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
     uint64_t* ka = w.keys_a.as<uint64_t>(); uint64_t* kb = w.keys_b.as<uint64_t>();
     uint32_t* va = w.vals_a.as<uint32_t>(); uint32_t* vb = w.vals_b.as<uint32_t>();
     for (int p = 0; p < P; ++p) {
-        k_radix_hist<<<nblk, RS_THREADS, 0, s>>>(ka, n, 8 * p, w.hist.as<uint32_t>(), nblk);
+        if (big) k_radix_hist<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ka, n, 8 * p, w.hist.as<uint32_t>(), nblk);
+        else k_radix_hist<RS_ITEMS_SMALL><<<nblk, RS_THREADS, 0, s>>>(ka, n, 8 * p, w.hist.as<uint32_t>(), nblk);
         exclusive_scan_u32(w.hist.as<uint32_t>(), w.hist.as<uint32_t>(), nh, w.scan_tmp.as<uint32_t>(), nullptr, s);
-        k_radix_scatter<<<nblk, RS_THREADS, 0, s>>>(ka, va, n, 8 * p, w.hist.as<uint32_t>(), nblk, kb, vb);
+        if (big) k_radix_scatter<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ka, va, n, 8 * p, w.hist.as<uint32_t>(), nblk, kb, vb);
+        else k_radix_scatter<RS_ITEMS_SMALL><<<nblk, RS_THREADS, 0, s>>>(ka, va, n, 8 * p, w.hist.as<uint32_t>(), nblk, kb, vb);
         std::swap(ka, kb); std::swap(va, vb);
     }
     HIP_TRY(hipGetLastError());
@@ -735,14 +776,20 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
     uint32_t* d_nseg = (uint32_t*)(w.misc.as<int32_t>() + 7);
     exclusive_scan_u32(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.scan_tmp.as<uint32_t>(), d_nseg, s);
     uint32_t nseg = 0;
-    HIP_TRY(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(w.seg_start.ensure(((size_t)nseg + 1) * 4));
+    if (host_nseg) {
+        HIP_TRY(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(w.seg_start.ensure(((size_t)nseg + 1) * 4));
+    } else {
+        HIP_TRY(w.seg_start.ensure((n_valid + 1) * 4));      // nseg <= n_valid: no read-back needed to size it
+    }
     k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
     HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
     k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
     HIP_TRY(hipGetLastError());
-    out->n_valid = n_valid; out->nseg = nseg; out->km = km; out->passes = P; out->sorted_keys = ka;
+    out->n_valid = n_valid; out->nseg = nseg; out->d_nseg = d_nseg; out->km = km; out->passes = P; out->sorted_keys = ka;
+    out->bbox_cells = 1;
+    for (int j = 0; j < 3; ++j) out->bbox_cells *= (uint64_t)((int64_t)misc[3 + j] - misc[j] + 1);
     return NDT_OK;
 }
 
@@ -750,7 +797,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
                      size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
     if (passes) *passes = 0;
     SortedCells sc;
-    int rc = sort_points_by_cell(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, s, &sc, err);
+    int rc = sort_points_by_cell(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, true, s, &sc, err);
     if (rc != NDT_OK) return rc;
     if (passes) *passes = sc.passes;
     if (sc.nseg == 0) return map_reserve(m, 1, s, err);
@@ -775,22 +822,24 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
 // Scan pre-processing: pcl::transformPointCloud + pcl::VoxelGrid(leaf) of process.cc:62-73 —
 // one centroid per occupied leaf cell, cells in PCL's index order (x fastest, z slowest); xyz only.
 int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, size_t n, size_t stride, const double* R, const double* t,
-                      DevBuf& ox, DevBuf& oy, DevBuf& oz, size_t* n_out, hipStream_t s, std::string& err) {
-    *n_out = 0;
+                      DevBuf& ox, DevBuf& oy, DevBuf& oz, const uint32_t** d_n_out, hipStream_t s, std::string& err) {
+    *d_n_out = nullptr;
     SortedCells sc;
-    int rc = sort_points_by_cell(w, leaf_kp, pts, nullptr, nullptr, n, stride, R, t, true, s, &sc, err);
+    int rc = sort_points_by_cell(w, leaf_kp, pts, nullptr, nullptr, n, stride, R, t, true, false, s, &sc, err);
     if (rc != NDT_OK) return rc;
-    HIP_TRY(ox.ensure((size_t)sc.nseg * 4 + 16)); HIP_TRY(oy.ensure((size_t)sc.nseg * 4 + 16)); HIP_TRY(oz.ensure((size_t)sc.nseg * 4 + 16));
-    if (sc.nseg == 0) return NDT_OK;
-    if (sc.n_valid / sc.nseg >= 24) {
-        k_segment_centroid<64><<<(unsigned)(((size_t)sc.nseg * 64 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.nseg, w.gx.as<float>(),
-                                                                                           w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+    if (sc.n_valid == 0) return NDT_OK;
+    HIP_TRY(ox.ensure(sc.n_valid * 4 + 16)); HIP_TRY(oy.ensure(sc.n_valid * 4 + 16)); HIP_TRY(oz.ensure(sc.n_valid * 4 + 16));
+    // lanes per cell from what is known without a read-back: at least n_valid / bbox_cells points per cell on average
+    const uint64_t cells_ub = std::min<uint64_t>(sc.bbox_cells, sc.n_valid);
+    if (sc.n_valid / cells_ub >= 24) {
+        k_segment_centroid<64><<<(unsigned)((cells_ub * 64 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, w.gx.as<float>(),
+                                                                                     w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
     } else {
-        k_segment_centroid<8><<<(unsigned)(((size_t)sc.nseg * 8 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.nseg, w.gx.as<float>(),
-                                                                                         w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+        k_segment_centroid<8><<<(unsigned)((cells_ub * 8 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, w.gx.as<float>(),
+                                                                                   w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
     }
     HIP_TRY(hipGetLastError());
-    *n_out = sc.nseg;
+    *d_n_out = sc.d_nseg;
     return NDT_OK;
 }
 
