@@ -114,6 +114,9 @@ def main():
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if ndev:
+            local %= ndev                         # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
     import lio_slam_amd as la
     from lio_slam_amd import synth
 
