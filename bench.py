@@ -224,6 +224,7 @@ def main():
         pair_scan = [p % len(scans) for p in range(a.batch)]
         guesses = [w[f"guess{(p % len(scans) + rank) % 8}"] if p < len(scans) else
                    w[f"T{(p % len(scans) + rank) % 8}"] @ synth.perturbation(rng) for p in range(a.batch)]
+        guesses = np.stack(guesses); pair_scan = np.asarray(pair_scan, np.int32)
         ndt.set_batch_sources(scans)                          # resident in HBM before the timed region
         pts_rank = float(sum(len(scans[s]) for s in pair_scan))
         step = lambda: ndt.align_batch_resident(guesses, pair_scan)

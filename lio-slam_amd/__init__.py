@@ -132,6 +132,11 @@ def lib():
     return L
 
 
+RESULT_DTYPE = np.dtype([("T", "f8", 16), ("H", "f8", 36), ("b", "f8", 6), ("chi2", "f8"), ("last_dx_norm", "f8"),
+                         ("n_effective", "i8"), ("iterations", "i4"), ("converged", "i4"), ("status", "i4"), ("reserved", "i4")])
+assert RESULT_DTYPE.itemsize == C.sizeof(Result)
+
+
 def default_config(**kw):
     cfg = Config()
     lib().ndt_default_config(C.byref(cfg))
@@ -269,14 +274,21 @@ class NDT:
         self._chk(lib().ndt_set_batch_sources(self._h, pts.ctypes.data, 12, off.ctypes.data, len(scans)))
 
     def align_batch_resident(self, guesses, pair_scan=None):
-        g = np.ascontiguousarray(np.stack([_T(T) for T in guesses]))
+        """guesses: (n, 4, 4) array or a list of 4x4 poses.  Results are unpacked in one vectorised step (a replay loop
+        in Python would otherwise spend more time building result dicts than the GPU spends aligning)."""
+        G = np.asarray(guesses, dtype=np.float64)
+        g = np.ascontiguousarray(G.transpose(0, 2, 1)).reshape(len(G), 16)       # column-major per pose
         n_pairs = len(g)
         ps = None if pair_scan is None else np.ascontiguousarray(pair_scan, dtype=np.int32)
-        res = (Result * n_pairs)()
-        self._chk(lib().ndt_align_batch_resident(self._h, None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data, res))
-        return [dict(rc=r.status, status=r.status, T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6),
-                     b=np.array(r.b), chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations,
-                     converged=bool(r.converged), last_dx_norm=r.last_dx_norm) for r in res]
+        res = np.zeros(n_pairs, RESULT_DTYPE)
+        self._chk(lib().ndt_align_batch_resident(self._h, None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data,
+                                                 C.cast(res.ctypes.data, C.POINTER(Result))))
+        T = res["T"].reshape(n_pairs, 4, 4).transpose(0, 2, 1)
+        H = res["H"].reshape(n_pairs, 6, 6)
+        return [dict(rc=int(st), status=int(st), T=T[i], H=H[i], b=res["b"][i], chi2=float(res["chi2"][i]),
+                     n_effective=int(res["n_effective"][i]), iterations=int(res["iterations"][i]),
+                     converged=bool(res["converged"][i]), last_dx_norm=float(res["last_dx_norm"][i]))
+                for i, st in enumerate(res["status"])]
 
     def getFinalTransformation(self): return self.final["T"]
     def hasConverged(self): return self.final["converged"]

@@ -679,7 +679,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
-    H_TRY(hipStreamSynchronize(s));           // pair_scan and st are free again
+    // no wait here: pair_scan (the caller's) and st stay alive until the loop's own synchronisation below
 
     h->b_pairs = n_pairs; h->b_rows = rows; h->b_has_pair_scan = pair_scan != nullptr;
     h->b_points = 0;
