@@ -1,0 +1,81 @@
+"""BASELINE.json configs[3] / configs[4] sizes on one GPU: a 20 M-point map with a 2 M-point source, and a replay batch of
+4096 (scan, guess) pairs.  The oracle checks what it can do in seconds (the map's voxel table, one evaluation of the
+2 M-point source, a handful of the 4096 pairs); the rest is checked through size-independent properties."""
+import numpy as np
+import pytest
+
+import lio_slam_amd as la
+from conftest import pose_error, rel_err
+from lio_slam_amd import synth
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small2():
+    return synth.make_config(2, small=True)          # 200 k-point yard map, 118 k-point HDL-64-shaped scan
+
+
+def test_20m_point_map_and_2m_point_source(small2):
+    c = small2
+    rng = np.random.default_rng(5)
+    # 20 M map points: the yard map tiled 10 x 10 with 300 m pitch and 1 cm jitter (coordinates up to ~3 km)
+    tiles = []
+    for ix in range(10):
+        for iy in range(10):
+            t = c["map"] + np.array([300.0 * ix, 300.0 * iy, 0.0], np.float32)
+            tiles.append((t + rng.normal(0, 0.01, t.shape)).astype(np.float32))
+    big = np.concatenate(tiles)
+    assert len(big) == 20_000_000
+    n = la.NDT(max_iterations=10, eps=1e-4); o = Oracle(max_iterations=10, eps=1e-4)
+    n.set_target(big); o.set_target(big)
+    assert n.num_voxels() == o.num_voxels() > 500_000
+    vg, vo = n.export_voxels(), o.export_voxels()
+    assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"]) and np.array_equal(vg["valid"], vo["valid"])
+    assert rel_err(vg["mean"], vo["mean"]) < 1e-9
+    sel = vo["valid"].astype(bool)
+    assert np.max(np.abs(vg["info"][sel] - vo["info"][sel]) / np.maximum(np.abs(vo["info"][sel]).max(axis=(1, 2), keepdims=True), 1e-30)) < 1e-5
+    # 2 M source points: the scan seen from 18 of the tiles, in one sensor frame
+    T = c["T_true"]
+    parts = []
+    for k in range(18):
+        ix, iy = k % 10, k // 10
+        w = synth.transform(T, c["scan"]) + np.array([300.0 * ix, 300.0 * iy, 0.0], np.float32)       # world points of tile k
+        parts.append(((w.astype(np.float64) - T[:3, 3]) @ T[:3, :3]).astype(np.float32))              # back into the sensor frame
+    src = np.concatenate(parts)[:2_000_000]
+    assert len(src) == 2_000_000
+    n.set_source(src); o.set_source(src)
+    kg, mg = n.source_cells(c["guess"]); ko, mo = o.source_cells(c["guess"])
+    assert np.array_equal(kg, ko) and np.array_equal(mg, mo)                # 2 M cell assignments and gate masks, bit for bit
+    eg, eo = n.eval(c["guess"]), o.eval(c["guess"])
+    assert eg["n_effective"] == eo["n_effective"] > 200_000      # the 200 k-point tiles are sparse: few voxels reach 6 points
+    assert rel_err(eg["H"], eo["H"]) < 1e-5 and rel_err(eg["b"], eo["b"]) < 1e-5
+    rg, ro = n.align(c["guess"]), o.align(c["guess"])
+    dt, dr = pose_error(rg["T"], ro["T"])
+    assert rg["iterations"] == ro["iterations"] and dt < 1e-4 and dr < 1e-5
+    et, _ = pose_error(rg["T"], T)
+    assert et < 0.2                                                       # sparse map: the optimum itself sits ~9 cm from the truth
+
+
+def test_4096_pair_replay(small2):
+    c = small2
+    rng = np.random.Generator(np.random.PCG64(9))
+    scans = [c["scan"][i::8] for i in range(8)]                                  # 8 scans of ~14.7 k points
+    guesses = np.stack([c["T_true"] @ synth.perturbation(rng, 0.05, 0.5, 0.5, 5.0) for _ in range(4096)])   # configs[4]: up to 0.5 m / 5 deg
+    pair_scan = np.arange(4096) % 8
+    n = la.NDT(max_iterations=10, eps=0.0)
+    n.set_target(c["map"])
+    res = n.align_batch(scans, guesses, pair_scan)
+    assert len(res) == 4096 and all(r["status"] == 0 and r["iterations"] == 10 for r in res)
+    err = np.array([pose_error(r["T"], c["T_true"])[0] for r in res])
+    assert np.median(err) < 0.15 and np.mean(err < 0.2) > 0.6                     # most hypotheses come home (sparse map, subsampled scans)
+    o = Oracle(max_iterations=10, eps=0.0); o.set_target(c["map"])
+    for p in (0, 1, 777, 2048, 4095):
+        o.set_source(scans[pair_scan[p]])
+        ro = o.align(guesses[p])
+        dt, dr = pose_error(res[p]["T"], ro["T"])
+        assert dt < 1e-4 and dr < 1e-5, (p, dt, dr)
+        assert rel_err(res[p]["H"], ro["H"]) < 1e-5
+    again = n.align_batch_resident(guesses, pair_scan)                           # deterministic: same bits on a second run
+    assert all(np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"]) for a, b in zip(res, again))
