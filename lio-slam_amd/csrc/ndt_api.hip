@@ -181,7 +181,7 @@ int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride, cons
 int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
-    if (n >= (1ull << 31)) { h->err = "more than 2^31 source points"; return NDT_ERR_INVALID_ARG; }
+    if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 source points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
     H_TRY(h->sraw.ensure(n * stride + 16));
     H_TRY(h->sx.ensure(n * 4 + 16)); H_TRY(h->sy.ensure(n * 4 + 16)); H_TRY(h->sz.ensure(n * 4 + 16));
