@@ -543,6 +543,7 @@ static int pcl_engine(ndt_handle* h, const ndt_pcl_params* prm, PclEngine* e) {
     e->kp = h->build_cfg.kp;
     e->partials = h->pcl_partials.as<double>() + ACC_N;
     e->d_row = h->pcl_partials.as<double>();
+    e->use_links = h->use_links;
     e->h_row = h->h_state->acc;          // pinned; the Gauss-Newton loop is not running while this mode is
     return NDT_OK;
 }

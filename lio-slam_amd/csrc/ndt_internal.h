@@ -95,6 +95,7 @@ struct PclEngine {            // what a pass needs from the handle
     double* partials;         // pcl_grid(n) rows of ACC_N doubles
     double* d_row;            // ACC_N doubles, device
     double* h_row;            // ACC_N doubles, pinned host
+    int use_links;            // 9 hashed cells + x-links instead of 27 hashed cells
 };
 int pcl_grid(size_t n);
 void pcl_matrix_from_vector(const double p[6], double T[16]);

@@ -38,6 +38,48 @@ struct PclPass {
     float r2f;            // (float)(resolution^2)
 };
 
+// the three cells of a row once their table entries are known: radius test, Magnusson weight, neighbour sums
+__device__ __forceinline__ void pcl_row_sums(const PclPass& pp, const float* qf, const int32_t* c, int32_t n1, int32_t n2, const uint32_t* fs,
+                                             const Payload* pay, double* G, double* S, double* Mm, double& score, double& nb, double& nvox) {
+    const double res = pp.kp.res_d;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+        const int32_t n0 = c[0] + pr - 1;
+        const bool vox = fs[pr] != SLOT_NONE && pay[pr].a.x != 0;
+        if (!__any(vox)) continue;                       // no lane of the wave has a voxel in this cell
+        nvox += vox ? 1.0 : 0.0;
+        const float o0 = __int_as_float(pay[pr].a.z), o1 = __int_as_float(pay[pr].a.w), o2 = pay[pr].b.x;
+        // radius search on the centroid cloud: float32 centroid, float32 squared distance, strictly inside
+        const float c0 = (float)((double)n0 * res + (double)o0), c1 = (float)((double)n1 * res + (double)o1), c2 = (float)((double)n2 * res + (double)o2);
+        const float f0 = qf[0] - c0, f1 = qf[1] - c1, f2 = qf[2] - c2;
+        const float dist2 = (f0 * f0 + f1 * f1) + f2 * f2;
+        const bool nbr = vox && dist2 < pp.r2f;
+        if (!__any(nbr)) continue;                       // ... or none within the radius: skip the float64 part (~60 instructions)
+        nb += nbr ? 1.0 : 0.0;
+        const double i22 = __int_as_float(pay[pr].a.y), i00 = pay[pr].b.y, i01 = pay[pr].b.z, i02 = pay[pr].b.w, i11 = pay[pr].c.x, i12 = pay[pr].c.y;
+        const double x0 = ((double)qf[0] - (double)n0 * res) - (double)o0;
+        const double x1 = ((double)qf[1] - (double)n1 * res) - (double)o1;
+        const double x2 = ((double)qf[2] - (double)n2 * res) - (double)o2;
+        const double g0 = (i00 * x0 + i01 * x1) + i02 * x2;
+        const double g1 = (i01 * x0 + i11 * x1) + i12 * x2;
+        const double g2 = (i02 * x0 + i12 * x1) + i22 * x2;
+        const double qv = (x0 * g0 + x1 * g1) + x2 * g2;
+        const double ex = exp(-pp.d2 * qv / 2.0);
+        const double e = pp.d2 * ex;
+        const bool ok = nbr && !(e > 1.0 || e < 0.0 || e != e);         // updateDerivatives' validity test
+        const double w = ok ? pp.d1 * e : 0.0;
+        score += ok ? -pp.d1 * ex : 0.0;
+        // selects, not multiplies by zero: the stand-in payload of a miss may give inf / NaN above
+        const double a0 = ok ? g0 : 0.0, a1 = ok ? g1 : 0.0, a2 = ok ? g2 : 0.0;
+        G[0] = fma(w, a0, G[0]); G[1] = fma(w, a1, G[1]); G[2] = fma(w, a2, G[2]);
+        S[0] = fma(w, ok ? i00 : 0.0, S[0]); S[1] = fma(w, ok ? i01 : 0.0, S[1]); S[2] = fma(w, ok ? i02 : 0.0, S[2]);
+        S[3] = fma(w, ok ? i11 : 0.0, S[3]); S[4] = fma(w, ok ? i12 : 0.0, S[4]); S[5] = fma(w, ok ? i22 : 0.0, S[5]);
+        const double w0 = w * a0, w1 = w * a1, w2 = w * a2;
+        Mm[0] = fma(w0, a0, Mm[0]); Mm[1] = fma(w0, a1, Mm[1]); Mm[2] = fma(w0, a2, Mm[2]);
+        Mm[3] = fma(w1, a1, Mm[3]); Mm[4] = fma(w1, a2, Mm[4]); Mm[5] = fma(w2, a2, Mm[5]);
+    }
+}
+
 // three cells (dx in -1..1) of the row (dy, dz): keys, resolve, payloads, neighbour sums.  Three probes at a time keep
 // the kernel at two waves per SIMD; nine at a time need 386 registers.
 __device__ __forceinline__ void pcl_row(const PclPass& pp, const float* qf, const int32_t* c, int dy, int dz, const int64_t* __restrict__ keys,
@@ -88,44 +130,56 @@ __device__ __forceinline__ void pcl_row(const PclPass& pp, const float* qf, cons
     Payload pay[3];
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) pay[pr] = load_payload(slots, fs[pr]);
-    const double res = pp.kp.res_d;
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {
-        const int32_t n0 = c[0] + pr - 1;
-        const bool vox = fs[pr] != SLOT_NONE && pay[pr].a.x != 0;
-        const float o0 = __int_as_float(pay[pr].a.z), o1 = __int_as_float(pay[pr].a.w), o2 = pay[pr].b.x;
-        const double i22 = __int_as_float(pay[pr].a.y), i00 = pay[pr].b.y, i01 = pay[pr].b.z, i02 = pay[pr].b.w, i11 = pay[pr].c.x, i12 = pay[pr].c.y;
-        // radius search on the centroid cloud: float32 centroid, float32 squared distance, strictly inside
-        const float c0 = (float)((double)n0 * res + (double)o0), c1 = (float)((double)n1 * res + (double)o1), c2 = (float)((double)n2 * res + (double)o2);
-        const float f0 = qf[0] - c0, f1 = qf[1] - c1, f2 = qf[2] - c2;
-        const float dist2 = (f0 * f0 + f1 * f1) + f2 * f2;
-        const double x0 = ((double)qf[0] - (double)n0 * res) - (double)o0;
-        const double x1 = ((double)qf[1] - (double)n1 * res) - (double)o1;
-        const double x2 = ((double)qf[2] - (double)n2 * res) - (double)o2;
-        const double g0 = (i00 * x0 + i01 * x1) + i02 * x2;
-        const double g1 = (i01 * x0 + i11 * x1) + i12 * x2;
-        const double g2 = (i02 * x0 + i12 * x1) + i22 * x2;
-        const double qv = (x0 * g0 + x1 * g1) + x2 * g2;
-        const double ex = exp(-pp.d2 * qv / 2.0);
-        const double e = pp.d2 * ex;
-        const bool nbr = vox && dist2 < pp.r2f;
-        const bool ok = nbr && !(e > 1.0 || e < 0.0 || e != e);         // updateDerivatives' validity test
-        const double w = ok ? pp.d1 * e : 0.0;
-        nb += nbr ? 1.0 : 0.0;
-        nvox += vox ? 1.0 : 0.0;
-        score += ok ? -pp.d1 * ex : 0.0;
-        // selects, not multiplies by zero: the stand-in payload of a miss may give inf / NaN above
-        const double a0 = ok ? g0 : 0.0, a1 = ok ? g1 : 0.0, a2 = ok ? g2 : 0.0;
-        G[0] = fma(w, a0, G[0]); G[1] = fma(w, a1, G[1]); G[2] = fma(w, a2, G[2]);
-        S[0] = fma(w, ok ? i00 : 0.0, S[0]); S[1] = fma(w, ok ? i01 : 0.0, S[1]); S[2] = fma(w, ok ? i02 : 0.0, S[2]);
-        S[3] = fma(w, ok ? i11 : 0.0, S[3]); S[4] = fma(w, ok ? i12 : 0.0, S[4]); S[5] = fma(w, ok ? i22 : 0.0, S[5]);
-        const double w0 = w * a0, w1 = w * a1, w2 = w * a2;
-        Mm[0] = fma(w0, a0, Mm[0]); Mm[1] = fma(w0, a1, Mm[1]); Mm[2] = fma(w0, a2, Mm[2]);
-        Mm[3] = fma(w1, a1, Mm[3]); Mm[4] = fma(w1, a2, Mm[4]); Mm[5] = fma(w2, a2, Mm[5]);
-    }
+    pcl_row_sums(pp, qf, c, n1, n2, fs, pay, G, S, Mm, score, nb, nvox);
 }
 
-template <bool HESS, bool GRAD>
+// The same row through the neighbour links: only the middle cell (dx = 0) is hashed; if a voxel sits at dx = +-1 the
+// middle cell is in the table too (as a voxel or as a ghost cell) and its entry holds their slots.
+// A row is three dependent round trips (keys -> entry -> neighbour payloads); the key read of the NEXT row is issued
+// before the current row is finished, so nine rows cost 19 trips instead of 27.
+struct RowProbe { int64_t want; uint32_t s0; int32_t n1, n2; bool live; Key2 ka, kb; };
+__device__ __forceinline__ RowProbe pcl_row_issue(const int32_t* c, int row, const int64_t* __restrict__ keys, uint32_t mask, bool point_ok) {
+    RowProbe r;
+    r.n1 = c[1] + row % 3 - 1; r.n2 = c[2] + row / 3 - 1;
+    r.live = point_ok && cell_ok(c[0]) && cell_ok(r.n1) && cell_ok(r.n2);
+    r.want = ndt_pack(c[0], r.n1, r.n2);
+    r.s0 = r.live ? ndt_hash_cell(c[0], r.n1, r.n2) & mask : 0u;
+    const Key2* kp = (const Key2*)(keys + r.s0);
+    r.ka = kp[0]; r.kb = kp[1];
+    return r;
+}
+__device__ __forceinline__ void pcl_row_finish(const PclPass& pp, const float* qf, const int32_t* c, const RowProbe& r, const int64_t* __restrict__ keys,
+                                               const VoxSlot* __restrict__ slots, uint32_t mask, double* G, double* S, double* Mm,
+                                               double& score, double& nb, double& nvox) {
+    const int64_t want = r.want;
+    const bool m0 = r.ka.x == want, m1 = r.ka.y == want, m2 = r.kb.x == want, m3 = r.kb.y == want;
+    const bool e0 = r.ka.x == NDT_KEY_EMPTY, e1 = r.ka.y == NDT_KEY_EMPTY, e2 = r.kb.x == NDT_KEY_EMPTY, e3 = r.kb.y == NDT_KEY_EMPTY;
+    const uint32_t off = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
+    const bool found = r.live && (m0 || (!e0 && (m1 || (!e1 && (m2 || (!e2 && m3))))));
+    uint32_t fsm = found ? (r.s0 + off) & mask : SLOT_NONE;
+    bool pending = r.live && !(m0 || e0 || m1 || e1 || m2 || e2 || m3 || e3);
+    uint32_t cur = (r.s0 + 4) & mask;
+    while (__any(pending)) {           // chains longer than four entries (rare)
+        const int64_t k = keys[cur];
+        const bool hit = pending && k == want, stop = pending && (hit || k == NDT_KEY_EMPTY);
+        fsm = hit ? cur : fsm;
+        pending = pending && !stop;
+        cur = pending ? (cur + 1) & mask : cur;
+    }
+    const int4* sp = (const int4*)(slots + (fsm != SLOT_NONE ? fsm : 0u));      // payload + links of the middle cell: one 64-byte line
+    const int4 a = sp[0];
+    const float4 b = *(const float4*)(sp + 1);
+    const int4 c2 = sp[2];
+    const bool have = fsm != SLOT_NONE;
+    uint32_t fs[3] = {have ? (uint32_t)c2.z : SLOT_NONE, fsm, have ? (uint32_t)c2.w : SLOT_NONE};   // link[0] = -x, link[1] = +x
+    Payload pay[3];
+    pay[1].a = a; pay[1].b = b; pay[1].c = make_float2(__int_as_float(c2.x), __int_as_float(c2.y));
+    pay[0] = load_payload(slots, fs[0]);
+    pay[2] = load_payload(slots, fs[2]);
+    pcl_row_sums(pp, qf, c, r.n1, r.n2, fs, pay, G, S, Mm, score, nb, nvox);
+}
+
+template <bool HESS, bool GRAD, bool LINKED>
 __global__ __launch_bounds__(PCL_THREADS) void k_pcl_pass(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                                           int64_t n, const int64_t* __restrict__ keys, const VoxSlot* __restrict__ slots,
                                                           uint32_t mask, PclPass pp, double* __restrict__ partials) {
@@ -147,7 +201,16 @@ __global__ __launch_bounds__(PCL_THREADS) void k_pcl_pass(const float* __restric
         if (!ok) { c[0] = c[1] = c[2] = 0; qf[0] = qf[1] = qf[2] = 0.f; x = y = z = 0.f; }   // nothing non-finite may reach the sums
         double G[3] = {0, 0, 0}, S[6] = {0, 0, 0, 0, 0, 0}, Mm[6] = {0, 0, 0, 0, 0, 0}, score = 0.0, nb = 0.0, nvox = 0.0;
 #pragma unroll 1
-        for (int row = 0; row < 9; ++row) pcl_row(pp, qf, c, row % 3 - 1, row / 3 - 1, keys, slots, mask, ok, G, S, Mm, score, nb, nvox);
+        for (int row = 0; row < 9 && !LINKED; ++row) pcl_row(pp, qf, c, row % 3 - 1, row / 3 - 1, keys, slots, mask, ok, G, S, Mm, score, nb, nvox);
+        if (LINKED) {
+            RowProbe next = pcl_row_issue(c, 0, keys, mask, ok);
+#pragma unroll 1
+            for (int row = 0; row < 9; ++row) {
+                const RowProbe cur = next;
+                if (row < 8) next = pcl_row_issue(c, row + 1, keys, mask, ok);
+                pcl_row_finish(pp, qf, c, cur, keys, slots, mask, G, S, Mm, score, nb, nvox);
+            }
+        }
         acc[PCL_ACC_NB] += nb;
         acc[PCL_ACC_VOX] += nvox;
         if (!__any(nb != 0.0)) continue;
@@ -212,6 +275,17 @@ __global__ __launch_bounds__(1024) void k_pcl_reduce(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------ host side
+
+static void launch_pass(const PclEngine& e, const PclPass& pp, int grid, bool with_gradient, bool with_hessian) {
+    const int64_t n = (int64_t)e.n;
+#define PCL_LAUNCH(H, G, L) k_pcl_pass<H, G, L><<<grid, PCL_THREADS, 0, e.stream>>>(e.sx, e.sy, e.sz, n, e.keys, e.slots, e.mask, pp, e.partials)
+    if (e.use_links) {
+        if (with_hessian && with_gradient) PCL_LAUNCH(true, true, true); else if (with_gradient) PCL_LAUNCH(false, true, true); else PCL_LAUNCH(true, false, true);
+    } else {
+        if (with_hessian && with_gradient) PCL_LAUNCH(true, true, false); else if (with_gradient) PCL_LAUNCH(false, true, false); else PCL_LAUNCH(true, false, false);
+    }
+#undef PCL_LAUNCH
+}
 
 namespace {
 
@@ -372,9 +446,7 @@ struct Driver {
         pp.r2f = (float)(e->kp.res_d * e->kp.res_d);
         const int grid = pcl_grid(e->n);
         const int64_t n = (int64_t)e->n;
-        if (with_hessian && with_gradient) k_pcl_pass<true, true><<<grid, PCL_THREADS, 0, e->stream>>>(e->sx, e->sy, e->sz, n, e->keys, e->slots, e->mask, pp, e->partials);
-        else if (with_gradient) k_pcl_pass<false, true><<<grid, PCL_THREADS, 0, e->stream>>>(e->sx, e->sy, e->sz, n, e->keys, e->slots, e->mask, pp, e->partials);
-        else k_pcl_pass<true, false><<<grid, PCL_THREADS, 0, e->stream>>>(e->sx, e->sy, e->sz, n, e->keys, e->slots, e->mask, pp, e->partials);
+        launch_pass(*e, pp, grid, with_gradient, with_hessian);
         k_pcl_reduce<<<1, 1024, 0, e->stream>>>(e->partials, grid, e->d_row);
         hipError_t rc = hipGetLastError();
         if (rc == hipSuccess) rc = hipMemcpyAsync(e->h_row, e->d_row, ACC_N * sizeof(double), hipMemcpyDeviceToHost, e->stream);
@@ -570,8 +642,7 @@ int pcl_time_pass(const PclEngine& e, const ndt_pcl_params& prm, const double p[
     const int grid = pcl_grid(e.n);
     hipEventRecord(a, e.stream);
     for (int i = 0; i < reps; ++i) {
-        if (with_hessian) k_pcl_pass<true, true><<<grid, PCL_THREADS, 0, e.stream>>>(e.sx, e.sy, e.sz, (int64_t)e.n, e.keys, e.slots, e.mask, pp, e.partials);
-        else k_pcl_pass<false, true><<<grid, PCL_THREADS, 0, e.stream>>>(e.sx, e.sy, e.sz, (int64_t)e.n, e.keys, e.slots, e.mask, pp, e.partials);
+        launch_pass(e, pp, grid, true, with_hessian);
     }
     hipEventRecord(b, e.stream);
     hr = hipEventSynchronize(b);

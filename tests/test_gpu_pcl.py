@@ -98,3 +98,22 @@ def test_errors():
         n.pcl_eval(np.zeros(6), outlier_ratio=1.5)
     with pytest.raises(la.NdtError):
         n.pcl_eval(np.array([0, 0, np.nan, 0, 0, 0.0]))
+
+
+def test_linked_rows_match_hashed_rows(golden, monkeypatch):
+    """27 hashed cells (NDT_NO_LINKS=1) and 9 hashed cells + x-links visit the same voxels in the same order: same bits."""
+    c = synth.make_config(1, small=True)
+    p = la.pcl_vector_from_matrix(c["guess"])
+    res = []
+    for no_links in (False, True):
+        if no_links:
+            monkeypatch.setenv("NDT_NO_LINKS", "1")
+        n = la.NDT(max_iterations=10, eps=1e-6)
+        half = len(c["map"]) // 2
+        n.set_target(c["map"][:half]); n.add_target(c["map"][half:])          # links rebuilt after a merge
+        n.set_source(c["scan"])
+        res.append((n.pcl_eval(p), n.pcl_align(c["guess"])))
+    (ea, ra), (eb, rb) = res
+    assert ea["n_neighbours"] == eb["n_neighbours"] and ea["score"] == eb["score"]
+    assert np.array_equal(ea["g"], eb["g"]) and np.array_equal(ea["H"], eb["H"])
+    assert np.array_equal(ra["T"], rb["T"]) and ra["iterations"] == rb["iterations"] and ra["evaluations"] == rb["evaluations"]
