@@ -171,18 +171,33 @@ __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float y
 // NEARBY7 through the neighbour links: only the point's own cell is hashed; its slot holds the slots of the six
 // face neighbours (ghost cells make sure a cell next to a voxel is always in the table).  Same probe order and the
 // same arithmetic as point_terms<7>, so both give identical bits.
-__device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
-                                                       const VoxSlot* __restrict__ slots, uint32_t mask, const EvalParams& ep,
-                                                       double* acc, int64_t* cell_key) {
+// first half: transform, cell, hash, and the two 16-byte key reads of the point's own cell (issued, not yet used)
+struct CentreProbe { uint32_t s0; Key2 ka, kb; };
+__device__ __forceinline__ CentreProbe centre_probe(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys, uint32_t mask,
+                                                    const EvalParams& ep) {
+    double q[3];
+    ndt_xform(P.R, P.t, xf, yf, zf, q);
+    int32_t c[3];
+    const bool ok = ndt_source_cell(ep.kp, q, c);
+    CentreProbe pr;
+    pr.s0 = ok ? ndt_hash_cell(c[0], c[1], c[2]) & mask : 0u;
+    const Key2* kp = (const Key2*)(keys + pr.s0);
+    pr.ka = kp[0]; pr.kb = kp[1];
+    return pr;
+}
+// second half: resolve the centre entry from the keys already read, then links, payloads, gate and fold.  The
+// transformed point and its cell are recomputed (27 flops) rather than carried across the software-pipeline stage.
+__device__ __forceinline__ unsigned point_terms_from_probe(const Pose& P, float xf, float yf, float zf, const CentreProbe& pr,
+                                                           const int64_t* __restrict__ keys, const VoxSlot* __restrict__ slots, uint32_t mask,
+                                                           const EvalParams& ep, double* acc, int64_t* cell_key) {
     double q[3];
     ndt_xform(P.R, P.t, xf, yf, zf, q);
     int32_t c[3];
     if (!ndt_source_cell(ep.kp, q, c)) { *cell_key = NDT_KEY_EMPTY; return 0; }
     const int64_t ckey = ndt_pack(c[0], c[1], c[2]);
     *cell_key = ckey;
-    const uint32_t s0 = ndt_hash_cell(c[0], c[1], c[2]) & mask;
-    const Key2* kp = (const Key2*)(keys + s0);
-    const Key2 ka = kp[0], kb = kp[1];
+    const uint32_t s0 = pr.s0;
+    const Key2 ka = pr.ka, kb = pr.kb;
     const bool m0 = ka.x == ckey, m1 = ka.y == ckey, m2 = kb.x == ckey, m3 = kb.y == ckey;
     const bool e0 = ka.x == NDT_KEY_EMPTY, e1 = ka.y == NDT_KEY_EMPTY, e2 = kb.x == NDT_KEY_EMPTY, e3 = kb.y == NDT_KEY_EMPTY;
     const uint32_t off = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
@@ -211,11 +226,17 @@ __device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, 
     Payload pay[7];
     pay[0].a = a; pay[0].b = b; pay[0].c = make_float2(__int_as_float(c2.x), __int_as_float(c2.y));
 #pragma unroll
-    for (int pr = 1; pr < 7; ++pr) pay[pr] = load_payload(slots, fs[pr]);
+    for (int prb = 1; prb < 7; ++prb) pay[prb] = load_payload(slots, fs[prb]);
     double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     const unsigned hitmask = gate_and_sum<7>(pay, fs, q, c, ep, S, g, acc);
     fold_point(P, xf, yf, zf, hitmask, S, g, acc);
     return hitmask;
+}
+__device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
+                                                       const VoxSlot* __restrict__ slots, uint32_t mask, const EvalParams& ep,
+                                                       double* acc, int64_t* cell_key) {
+    const CentreProbe pr = centre_probe(P, xf, yf, zf, keys, mask, ep);
+    return point_terms_from_probe(P, xf, yf, zf, pr, keys, slots, mask, ep, acc, cell_key);
 }
 
 template <int K, bool CELLS, bool LINKED>
@@ -273,12 +294,27 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
     double acc[ACC_N];
 #pragma unroll
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
-    while (i < hi) {
-        int64_t ck;
-        if (LINKED) point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
-        else point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
-        i += (int64_t)gridDim.x * RES_THREADS;
-        if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    if (LINKED) {
+        // one software-pipeline stage: the centre keys of the NEXT point are requested before the current point is worked
+        // on, so a lane waits for three dependent round trips per point instead of four
+        const int64_t stride = (int64_t)gridDim.x * RES_THREADS;
+        CentreProbe pr = centre_probe(P, xf, yf, zf, keys, mask, ep);
+        while (i < hi) {
+            const int64_t in = i + stride;
+            float xn = 0.f, yn = 0.f, zn = 0.f;
+            if (in < hi) { xn = xs[in]; yn = ys[in]; zn = zs[in]; }
+            const CentreProbe prn = centre_probe(P, xn, yn, zn, keys, mask, ep);
+            int64_t ck;
+            point_terms_from_probe(P, xf, yf, zf, pr, keys, slots, mask, ep, acc, &ck);
+            pr = prn; xf = xn; yf = yn; zf = zn; i = in;
+        }
+    } else {
+        while (i < hi) {
+            int64_t ck;
+            point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+            i += (int64_t)gridDim.x * RES_THREADS;
+            if (i < hi) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+        }
     }
     block_store_row<RES_THREADS>(acc, partials + ((size_t)pair * rows_per_pair + blockIdx.x) * ACC_N);
 }
