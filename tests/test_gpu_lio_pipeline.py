@@ -121,3 +121,26 @@ def test_replay_matches_python_loop_and_truth(tmp_path):
     last = rows[max(rows)]
     assert np.linalg.norm(last[7:10]) > 1.5 and int(last[0]) >= 4                 # it drove, and merged keyframes
     print("worst |engine - oracle loop| %.2e m, worst |engine - truth| %.3f m" % (worst_t, worst_truth))
+
+
+def test_replay_with_the_ndt_hessian_as_information(tmp_path):
+    """SURVEY.md §8(f) N2 inside the loop: PointCloudFactor weighted by the engine's Hessian (made positive definite by
+    ndt_information_from_hessian) instead of the constant diagonal of process.cc:205-208.  No oracle loop here (the
+    property checked is that the estimate stays on the true motion and the optimiser accepts the matrix every frame)."""
+    from oracle import lio_oracle as lo
+    m, T_il, imu, ts, scans = _stream()
+    path = tmp_path / "stream.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5d", NEED, LEAF, ACC_W, GYR_W, 1.0)); f.write(np.ascontiguousarray(T_il.T).tobytes())
+        f.write(struct.pack("<d", len(imu))); f.write(np.ascontiguousarray(imu).tobytes())
+        f.write(struct.pack("<d", len(scans)))
+        for t, s in zip(ts, scans):
+            f.write(struct.pack("<2d", t, len(s))); f.write(np.ascontiguousarray(s, np.float32).tobytes())
+    out = subprocess.run([EXE, str(path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = {int(v[0]): np.array(v[1:], float) for v in (l.split() for l in out.stdout.strip().split("\n")) if v[1] != "skipped"}
+    assert len(rows) >= 25
+    for k, g in rows.items():
+        Tt = m.pose(ts[k])
+        assert np.linalg.norm(g[7:10] - Tt[:3, 3]) < 0.02, (k, g[7:10], Tt[:3, 3])
+        assert np.linalg.norm(lo.log_R(lo.q_to_R(g[3:7]).T @ Tt[:3, :3])) < 0.02
