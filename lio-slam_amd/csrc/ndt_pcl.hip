@@ -640,15 +640,15 @@ int pcl_time_pass(const PclEngine& e, const ndt_pcl_params& prm, const double p[
     if (hr == hipSuccess) hr = hipEventCreate(&b);
     if (hr != hipSuccess) { err = hipGetErrorString(hr); return NDT_ERR_HIP; }
     const int grid = pcl_grid(e.n);
-    hipEventRecord(a, e.stream);
+    (void)hipEventRecord(a, e.stream);
     for (int i = 0; i < reps; ++i) {
         launch_pass(e, pp, grid, true, with_hessian);
     }
-    hipEventRecord(b, e.stream);
+    (void)hipEventRecord(b, e.stream);
     hr = hipEventSynchronize(b);
     float ms = 0.f;
     if (hr == hipSuccess) hr = hipEventElapsedTime(&ms, a, b);
-    hipEventDestroy(a); hipEventDestroy(b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     if (hr != hipSuccess) { err = hipGetErrorString(hr); return NDT_ERR_HIP; }
     if (us_per_launch) *us_per_launch = 1000.0 * (double)ms / (double)reps;
     return NDT_OK;
