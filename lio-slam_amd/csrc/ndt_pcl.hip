@@ -445,7 +445,6 @@ struct Driver {
         pp.d1 = d1; pp.d2 = d2; pp.kp = e->kp;
         pp.r2f = (float)(e->kp.res_d * e->kp.res_d);
         const int grid = pcl_grid(e->n);
-        const int64_t n = (int64_t)e->n;
         launch_pass(*e, pp, grid, with_gradient, with_hessian);
         k_pcl_reduce<<<1, 1024, 0, e->stream>>>(e->partials, grid, e->d_row);
         hipError_t rc = hipGetLastError();
