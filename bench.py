@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_BATCH = 64      # pairs per step per GPU: configs[4] replays 4096 pairs over 8 GPUs (512 per GPU), a step is a slice of that
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -34,11 +35,12 @@ def algorithmic_bytes_per_point(k, h):
     return 12.0 + 8.0 * k + 40.0 * h
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic_r01.json), or None."""
+def measured_traffic(kernel, points_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic_r01.json); None when
+    the file holds no measurement of a launch of this size."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        return d[kernel]["bytes_per_launch"]
+        return d[kernel]["bytes_per_launch"] if d[kernel]["points_per_launch"] == int(points_per_launch) else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -98,7 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10, help="Gauss-Newton iterations per align (fixed)")
     ap.add_argument("--nearby", type=int, default=7)
-    ap.add_argument("--batch", type=int, default=16, help="scan-to-map pairs aligned together per step (replay mode)")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="scan-to-map pairs aligned together per step (replay mode)")
     ap.add_argument("--mode", choices=["replay", "sharded"], default="replay")
     ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -280,7 +282,7 @@ def main():
         "scans_per_s": a.steps * (a.batch * world if a.mode == "replay" else 1) / el,
         "map_build_ms": build_ms, "keyframe_merge_ms": merge_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(kname.replace("k_residual_batch", "k_residual_batch") if a.batch == 16 or a.mode != "replay" else ""),
+                     "traffic": measured_traffic(kname, ppl),
                      "traffic_source": "profiles/traffic_r01.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, same workload)",
                      "kernel": kname, "kernel_avg_us": k_us, "bytes_per_point": bpp, "hits_per_point": h,
                      "points_per_launch": int(ppl),

@@ -72,6 +72,7 @@ struct ndt_handle {
     DevBuf comm_rows;            // [2][ACC_N] doubles: all-reduce send / receive rows
     // offline replay batch
     DevBuf braw, bx, by, bz, boff, bpair, bstates, bpartials, bdone;
+    size_t b_group = 0;                        // pairs per launch group of the resident batch
     std::vector<int64_t> b_offsets; int64_t b_max_pts = 0;
     size_t b_pairs = 0; int b_rows = 0; bool b_has_pair_scan = false; double b_points = 0;   // geometry of the resident batch
 };
@@ -114,6 +115,8 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return nullptr;
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess) residual_set_cu_count(n_cu);
     ndt_handle* h = new (std::nothrow) ndt_handle();
     if (!h) return nullptr;
     h->cfg = *cfg;
@@ -676,27 +679,48 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     for (size_t p = 0; p < n_pairs; ++p) state_from_T(&st[p], guesses + 16 * p);
     H_TRY(h->bstates.ensure(n_pairs * sizeof(GnState)));
     H_TRY(hipMemcpyAsync(h->bstates.p, st.data(), n_pairs * sizeof(GnState), hipMemcpyHostToDevice, s));
-    const int rows = residual_grid((size_t)max_pts, n_pairs);
+    // Launch groups: with eight pairs or more the batch goes in two launches per iteration, and each launch carries the
+    // reduction + Gauss-Newton step of the OTHER group's previous launch as a few extra blocks (launch_residual_batch's
+    // `carry`), so that the latency-bound step never has the GPU to itself.
+    const size_t CH = 32768;                  // gridDim.y limit is 65535
+    const size_t group = n_pairs >= 8 ? std::min(CH, (n_pairs + 1) / 2) : n_pairs;
+    const size_t n_groups = (n_pairs + group - 1) / group;
+    const int rows = residual_grid((size_t)max_pts, group);
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
     // no wait here: pair_scan (the caller's) and st stay alive until the loop's own synchronisation below
 
-    h->b_pairs = n_pairs; h->b_rows = rows; h->b_has_pair_scan = pair_scan != nullptr;
+    h->b_pairs = n_pairs; h->b_rows = rows; h->b_has_pair_scan = pair_scan != nullptr; h->b_group = group;
     h->b_points = 0;
     for (size_t p = 0; p < n_pairs; ++p) { const size_t sc = pair_scan ? (size_t)pair_scan[p] : p; h->b_points += (double)(scan_offsets[sc + 1] - scan_offsets[sc]); }
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     GnState* dst = h->bstates.as<GnState>();
     const int32_t* dps = pair_scan ? h->bpair.as<int32_t>() : nullptr;
-    const size_t CH = 32768;                  // gridDim.y limit is 65535
+    struct { bool has = false; size_t p0 = 0; int np = 0, do_solve = 0, force = 0; } pend;      // a group whose rows wait to be reduced
+    auto carried = [&]() {
+        CarriedReduce c;
+        c.partials = h->bpartials.as<double>() + pend.p0 * (size_t)rows * ACC_N; c.states = dst + pend.p0; c.n_done = h->bdone.as<int32_t>();
+        c.sp = sp; c.rows_per_pair = rows; c.n_pairs = pend.np; c.do_solve = pend.do_solve; c.force = pend.force;
+        return c;
+    };
+    auto flush = [&]() {      // the pending reduction as a launch of its own (before the host looks, or when there is one group only)
+        if (!pend.has) return;
+        launch_reduce_solve_batch(h->bpartials.as<double>() + pend.p0 * (size_t)rows * ACC_N, rows, dst + pend.p0, pend.np, sp, pend.do_solve,
+                                  pend.force, h->bdone.as<int32_t>(), s);
+        pend.has = false;
+    };
     auto pass = [&](int do_solve, int force) {
-        for (size_t p0 = 0; p0 < n_pairs; p0 += CH) {
-            const int np = (int)std::min(CH, n_pairs - p0);
+        for (size_t g = 0; g < n_groups; ++g) {
+            const size_t p0 = g * group;
+            const int np = (int)std::min(group, n_pairs - p0);
+            if (n_groups == 1) flush();           // a group's next residual needs its own step first
+            const CarriedReduce c = carried();
             launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(), dps, h->map.keys,
-                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, h->use_links, s);
-            launch_reduce_solve_batch(h->bpartials.as<double>() + p0 * (size_t)rows * ACC_N, rows, dst + p0, np, sp, do_solve, force,
-                                      h->bdone.as<int32_t>(), s);
+                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, h->use_links,
+                                  pend.has ? &c : nullptr, s);
+            pend.has = true; pend.p0 = p0; pend.np = np; pend.do_solve = do_solve; pend.force = force;
         }
     };
     const int max_it = h->cfg.max_iterations;
@@ -704,6 +728,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     for (int queued = 0; queued < max_it;) {
         const int m = std::min(chunk, max_it - queued);
         for (int i = 0; i < m; ++i) pass(1, 0);
+        flush();
         queued += m;
         H_TRY(hipGetLastError());
         int32_t n_done = 0;
@@ -716,6 +741,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     H_TRY(hipStreamSynchronize(s));
     if (h->cfg.final_eval) {
         pass(0, 1);
+        flush();
         H_TRY(hipGetLastError());
         H_TRY(hipMemcpyAsync(st.data(), dst, n_pairs * sizeof(GnState), hipMemcpyDeviceToHost, s));
         H_TRY(hipStreamSynchronize(s));
@@ -815,10 +841,16 @@ int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, doub
     H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
+    // the launches the batched loop makes: one per group of pairs, here back to back and without the carried reductions
+    const size_t group = h->b_group ? h->b_group : h->b_pairs, n_groups = (h->b_pairs + group - 1) / group;
     auto pass = [&]() {
-        launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(),
-                              h->b_has_pair_scan ? h->bpair.as<int32_t>() : nullptr, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
-                              h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, 0, (int)h->b_pairs, 1, h->use_links, h->stream);
+        for (size_t g = 0; g < n_groups; ++g) {
+            const size_t p0 = g * group;
+            launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(),
+                                  h->b_has_pair_scan ? h->bpair.as<int32_t>() : nullptr, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
+                                  h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, (int)p0, (int)std::min(group, h->b_pairs - p0), 1,
+                                  h->use_links, nullptr, h->stream);
+        }
     };
     for (int i = 0; i < 3; ++i) pass();
     H_TRY(hipEventRecord(e0, h->stream));
@@ -828,8 +860,8 @@ int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, doub
     float ms = 0.f;
     H_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *us_per_launch = 1e3 * (double)ms / reps;
-    if (points_per_launch) *points_per_launch = h->b_points;
+    *us_per_launch = 1e3 * (double)ms / ((double)reps * (double)n_groups);
+    if (points_per_launch) *points_per_launch = h->b_points / (double)n_groups;      // mean over the groups
     if (hits_per_point) {   // measured at the poses the batch ended at
         launch_reduce_solve_batch(h->bpartials.as<double>(), h->b_rows, h->bstates.as<GnState>(), (int)h->b_pairs, sp, 0, 1, h->bdone.as<int32_t>(), h->stream);
         std::vector<GnState> st(h->b_pairs);

@@ -269,6 +269,18 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
+// A batched residual launch can carry the reduction + Gauss-Newton step of ANOTHER group of pairs (whose residual rows the
+// previous launch wrote): a few extra blocks at the front of the grid.  The latency-bound step then runs underneath the
+// residual blocks instead of as a launch of its own with the GPU idle around it.
+struct PiggyReduce {
+    const double* partials;   // rows of the carried group (nullptr: nothing carried)
+    GnState* states;
+    int32_t* n_done;
+    SolveParams sp;
+    int32_t rows_per_pair, n_pairs, do_solve, force;
+};
+__device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done);
+
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
 // pair's scan.  Scans are stored back to back in xs/ys/zs; pair p reads scan pair_scan[p] (or p) and its own GnState.
 template <int K, bool LINKED>
@@ -277,8 +289,13 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
                                                                 const int32_t* __restrict__ pair_scan, const int64_t* __restrict__ keys,
                                                                 const VoxSlot* __restrict__ slots, uint32_t mask,
                                                                 const GnState* __restrict__ states, EvalParams ep,
-                                                                double* __restrict__ partials, int rows_per_pair, int force) {
-    const int pair = blockIdx.y;
+                                                                double* __restrict__ partials, int rows_per_pair, int force, PiggyReduce pg, int pg_rows) {
+    if ((int)blockIdx.y < pg_rows) {          // the first pg_rows grid rows: one block per carried pair
+        const int cp = blockIdx.y * gridDim.x + blockIdx.x;
+        if (cp < pg.n_pairs) reduce_solve_pair(pg.partials + (size_t)cp * pg.rows_per_pair * ACC_N, pg.rows_per_pair, pg.states + cp, pg.sp, pg.do_solve, pg.force, pg.n_done);
+        return;
+    }
+    const int pair = blockIdx.y - pg_rows;
     const int scan = pair_scan ? pair_scan[pair] : pair;
     const int64_t lo = scan_off[scan], hi = scan_off[scan + 1];
     const GnState* st = states + pair;
@@ -322,16 +339,26 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 // Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
 // the whole launch is small (latency-bound: every wave should be resident at once); up to 8 points per lane once
 // there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
+static int g_cu_count = 256;
+void residual_set_cu_count(int n) { if (n > 0) g_cu_count = n; }
 int residual_grid(size_t n, size_t problems) {
     if (problems <= 1) {                              // k_residual: 512-thread blocks, one point per lane up to 2048 blocks
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
         return (int)(g < 1 ? 1 : g > 2048 ? 2048 : g);
     }
-    const size_t total = n * problems;
-    size_t ppt = total / ((size_t)4096 * 64);        // keep >= ~4 waves per SIMD
-    if (ppt < 1) ppt = 1;
-    if (ppt > 8) ppt = 8;
-    size_t g = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
+    // Batched launches: 256-thread blocks, two resident per CU (241 VGPRs), each lane works through `ppt` points.  The
+    // grid is chosen against the tail effect: time ~ (rounds of resident blocks) x (points per lane + 2 for the block's
+    // reduction and row store), ties to the longer lane loop: 8 pairs of 118 k points run as 464 blocks of 8 points per
+    // lane (one round) rather than 528 blocks of 7 (two rounds); large batches settle on 8 (measured: DESIGN.md §5).
+    const size_t resident = (size_t)2 * (size_t)g_cu_count;
+    size_t best_ppt = 1, best_cost = ~(size_t)0;
+    for (size_t ppt = 8; ppt >= 1; --ppt) {
+        const size_t rows = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
+        const size_t rounds = (rows * problems + resident - 1) / resident;
+        const size_t cost = rounds * (ppt + 2);
+        if (cost < best_cost) { best_cost = cost; best_ppt = ppt; }
+    }
+    size_t g = (n + RES_THREADS * best_ppt - 1) / (RES_THREADS * best_ppt);
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
     return (int)g;
@@ -494,11 +521,9 @@ __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp,
 
 #define BRED_THREADS 256
 // batched form: one block per pair; counts the pairs that finish in *n_done
-__global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
-                                                                     SolveParams sp, int do_solve, int force, int32_t* n_done) {
+__device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done) {
     __shared__ double sm[BRED_THREADS / 32][ACC_N + 1];
-    GnState* st = states + blockIdx.x;
-    reduce_rows<BRED_THREADS / 32>(partials + (size_t)blockIdx.x * rows_per_pair * ACC_N, rows_per_pair, sm, true);
+    reduce_rows<BRED_THREADS / 32>(partials, rows_per_pair, sm, true);
     if (!force && st->done) return;
     if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
     if (do_solve && threadIdx.x == 0) {
@@ -509,18 +534,29 @@ __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const doubl
         if (st->done) atomicAdd(n_done, 1);
     }
 }
+__global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
+                                                                     SolveParams sp, int do_solve, int force, int32_t* n_done) {
+    reduce_solve_pair(partials + (size_t)blockIdx.x * rows_per_pair * ACC_N, rows_per_pair, states + blockIdx.x, sp, do_solve, force, n_done);
+}
 
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
                            const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
-                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, hipStream_t s) {
-    dim3 grid((unsigned)rows_per_pair, (unsigned)n_pairs);
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, const CarriedReduce* carry, hipStream_t s) {
+    PiggyReduce pg{};
+    int pg_rows = 0;
+    if (carry && carry->n_pairs > 0) {
+        pg.partials = carry->partials; pg.states = carry->states; pg.n_done = carry->n_done; pg.sp = carry->sp;
+        pg.rows_per_pair = carry->rows_per_pair; pg.n_pairs = carry->n_pairs; pg.do_solve = carry->do_solve; pg.force = carry->force;
+        pg_rows = (carry->n_pairs + rows_per_pair - 1) / rows_per_pair;
+    }
+    dim3 grid((unsigned)rows_per_pair, (unsigned)(n_pairs + pg_rows));
     const int32_t* ps = pair_scan ? pair_scan + pair0 : nullptr;
     // without pair_scan pair p reads scan p, so the offsets are shifted together with the states
     const int64_t* so = pair_scan ? scan_off : scan_off + pair0;
     double* pp = partials + (size_t)pair0 * rows_per_pair * ACC_N;
-    if (ep.nearby == 7 && linked) k_residual_batch<7, true><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
-    else if (ep.nearby == 7) k_residual_batch<7, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
-    else k_residual_batch<1, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    if (ep.nearby == 7 && linked) k_residual_batch<7, true><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
+    else if (ep.nearby == 7) k_residual_batch<7, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
+    else k_residual_batch<1, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
 }
 void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
                                int do_solve, int force, int32_t* n_done, hipStream_t s) {

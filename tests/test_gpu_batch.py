@@ -43,6 +43,7 @@ def test_batch_matches_oracle_and_single():
     # without pair_scan: one scan per pair
     res2 = n.align_batch(scans[:3], [guesses[0], guesses[2], guesses[4]])
     for a, b in zip(res2, (res[0], res[2], res[4])):
-        assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"])   # same launch geometry -> same bits
+        # the grid (points per lane) is chosen per batch size, so the summation tree differs: last bits only
+        assert pose_error(a["T"], b["T"])[0] < 1e-9 and rel_err(a["H"], b["H"]) < 1e-10
     with pytest.raises(la.NdtError):
         n.align_batch(scans[:3], guesses[:2])

@@ -8,9 +8,9 @@ ndt = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
 ndt.set_target(w["map"]); ndt.set_source(w["scan"])
 for _ in range(n_align):
     r = ndt.align(w["guess"])
-if len(sys.argv) > 2:      # also a few batched aligns (16 pairs)
+if len(sys.argv) > 2:      # also a few batched aligns (bench.py's default batch)
     scans = [w[f"scan{j}"] for j in range(8)]
     ndt.set_batch_sources(scans)
     for _ in range(int(sys.argv[2])):
-        ndt.align_batch_resident([w[f"guess{p % 8}"] for p in range(16)], [p % 8 for p in range(16)])
+        ndt.align_batch_resident([w[f"guess{p % 8}"] for p in range(bench.DEFAULT_BATCH)], [p % 8 for p in range(bench.DEFAULT_BATCH)])
 print("done", r["iterations"], ndt.num_voxels())
