@@ -15,7 +15,7 @@ SENSORS = {
     # name: (rings, min_elev_deg, max_elev_deg, azimuth_steps)
     "vlp16": (16, -15.0, 15.0, 1875),       # 30 000 rays  (VLP-16.urdf.xacro:4)
     "hdl64": (64, -24.8, 2.0, 1875),        # 120 000 rays
-    "dense128": (128, -25.0, 15.0, 15625),  # 2 000 000 rays
+    "dense128": (128, -24.8, 2.0, 15625),   # 2 000 000 rays, the HDL-64 shape's field of view (nearly every ray returns)
 }
 
 
