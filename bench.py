@@ -233,7 +233,9 @@ def main():
         # yard) against a 20 M-point map of that yard; the source is cut into contiguous ranges, one per rank
         guess, T = w["guess"], w["T_true"]
         big_map, scan_all = load_dense_workload(w, rank, world if use_dist else 1, dist)
-        ndt.set_target(big_map); n_vox = ndt.num_voxels(); n_map = len(big_map); del big_map
+        ndt.set_target(big_map); ndt.synchronize()
+        t0 = time.perf_counter(); ndt.set_target(big_map); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
+        n_vox = ndt.num_voxels(); n_map = len(big_map); del big_map
         lo, hi = shard_range(len(scan_all), rank, world)
         if use_dist:
             ids = [la.NDT.comm_unique_id() if rank == 0 else None]

@@ -77,7 +77,7 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 
 // ------------------------------------------------------------------ pass 1: world point, packed key, bbox
 
-// misc layout (int32): [0..2] min cell, [3..5] max cell, [6] n_valid, [7] nseg
+// misc layout (int32): [0..2] min cell, [3..5] max cell, [6] n_valid, [7] nseg, [8..11] flag sums, [12] big segments
 // Same-address global atomics from thousands of blocks serialise (~11 ns each), so every block writes one row
 // of partials and a single block folds the rows.
 #define TK_MAX_BLOCKS 1024
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
         misc[threadIdx.x] = r;
     }
     if (threadIdx.x == 7) misc[7] = 0;
+    if (threadIdx.x == 12) misc[12] = 0;
 }
 
 // pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
@@ -434,21 +435,78 @@ __global__ void k_gather_sorted(const uint32_t* sv, size_t n, const float* tx, c
 }
 
 // One SEG_LANES-lane group per segment (= one voxel of the batch): strided sums in voxel-local float64
-// coordinates over the sorted points, xor-tree over the group, then lane 0 claims / finds the hash slot, merges
-// and finalises.  SEG_LANES is 8 for sparse batches and 64 (a whole wave) when voxels hold many points.
+// coordinates over the sorted points, xor-tree over the group, then lane 0 claims / finds the hash slot and merges.
+// SEG_LANES is 8 for sparse batches and 64 (a whole wave) when voxels hold many points.  The eigen-decomposition and
+// the float32 payload (a long serial float64 chain) are left to k_finalize_segments, which runs one voxel per lane
+// on every lane instead of on one lane per group here (k_segment_merge<64> on 2 M points: 77 -> see DESIGN.md §5).
+// Segments far longer than the rest (the ground voxels next to the trajectory hold tens of thousands of points while
+// the average voxel holds a hundred) would each keep one SEG_LANES group busy long after the launch has drained:
+// those above `big` points are listed here and summed by a 1024-thread block each (k_big_sums); k_segment_merge
+// then takes their sums from big_sums instead of looping.  The list order is arbitrary, each sum is not.
+#define BIG_THREADS 1024
+__global__ void k_big_list(const uint32_t* seg_start, uint32_t nseg, uint32_t big, uint32_t* big_pos, uint32_t* big_list, uint32_t* big_count) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    uint32_t pos = 0xFFFFFFFFu;
+    if (seg_start[g + 1] - seg_start[g] > big) { pos = atomicAdd(big_count, 1u); big_list[pos] = g; }
+    big_pos[g] = pos;
+}
+__global__ __launch_bounds__(BIG_THREADS) void k_big_sums(const uint32_t* big_list, const uint32_t* big_count, const uint64_t* sk, const uint32_t* seg_start,
+                                                          const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg, double* big_sums) {
+    if (blockIdx.x >= *big_count) return;
+    __shared__ double sm[BIG_THREADS / 64][9];
+    const uint32_t g = big_list[blockIdx.x];
+    const uint32_t s = seg_start[g], e = seg_start[g + 1];
+    int32_t c[3];
+    ndt_unpack(sortkey_to_packed(sk[s], km), c[0], c[1], c[2]);
+    const double o0 = (double)c[0] * cfg.kp.res_d, o1 = (double)c[1] * cfg.kp.res_d, o2 = (double)c[2] * cfg.kp.res_d;
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * BIG_THREADS) {       // four loads per array in flight, added in index order
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * BIG_THREADS;
+            const bool in = i < e;
+            x[u] = in ? tx[i] : 0.f; y[u] = in ? ty[i] : 0.f; z[u] = in ? tz[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * BIG_THREADS >= e) break;
+            const double d0 = (double)x[u] - o0, d1 = (double)y[u] - o1, d2 = (double)z[u] - o2;
+            a[0] += d0; a[1] += d1; a[2] += d2;
+            a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+            a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sm[threadIdx.x >> 6][j] = a[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double r = sm[0][threadIdx.x];
+        for (int w = 1; w < BIG_THREADS / 64; ++w) r += sm[w][threadIdx.x];
+        big_sums[(size_t)blockIdx.x * 9 + threadIdx.x] = r;
+    }
+}
+
 template <int SEG_LANES>
 __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg,
                                                        const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
-                                                       VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
-                                                       uint32_t* entry_flag) {
+                                                       int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
+                                                       uint32_t* entry_flag, uint32_t* seg_slot, const uint32_t* big_pos, const double* big_sums) {
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     bool act = g < nseg;
-    uint32_t s = 0, e = 0;
+    uint32_t s = 0, e = 0, bp = 0xFFFFFFFFu;
     int64_t key = 0;
     double org[3] = {0, 0, 0};
     if (act) {
-        s = seg_start[g]; e = seg_start[g + 1];
+        s = seg_start[g]; e = seg_start[g + 1]; bp = big_pos[g];
         key = sortkey_to_packed(sk[s], km);
         int32_t c[3];
         ndt_unpack(key, c[0], c[1], c[2]);
@@ -456,7 +514,8 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
         for (int j = 0; j < 3; ++j) org[j] = (double)c[j] * cfg.kp.res_d;
     }
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = s + l; i < e; i += SEG_LANES) {
+    const uint32_t e_loop = bp == 0xFFFFFFFFu ? e : s;          // a big segment was summed by k_big_sums
+    for (uint32_t i = s + l; i < e_loop; i += SEG_LANES) {
         double d0 = (double)tx[i] - org[0], d1 = (double)ty[i] - org[1], d2 = (double)tz[i] - org[2];
         a[0] += d0; a[1] += d1; a[2] += d2;
         a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
@@ -467,6 +526,10 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
 #pragma unroll
         for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
     if (!act || l != 0) return;
+    if (bp != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a[j] = big_sums[(size_t)bp * 9 + j];
+    }
 
     const int32_t nb = (int32_t)(e - s);
     double mu[3] = {a[0] / nb, a[1] / nb, a[2] / nb};
@@ -485,7 +548,7 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
         if ((int64_t)prev == key) break;
         slot = (slot + 1) & mask;
     }
-    VoxSlot* sl = &slots[slot];
+    seg_slot[g] = (uint32_t)slot;
     double* mp = mean + slot * 3;
     double* cp = cov + slot * 6;
     int32_t ntot = nb;
@@ -516,7 +579,19 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
 #pragma unroll
     for (int j = 0; j < 6; ++j) cp[j] = cv[j];
     counts[slot] = ntot;
-    finalize_slot(sl, ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+}
+// one voxel of the batch per lane: regularised inverse + payload from the merged statistics
+__global__ __launch_bounds__(256) void k_finalize_segments(const uint32_t* seg_slot, uint32_t nseg, MapBuildCfg cfg, VoxSlot* slots,
+                                                           const int32_t* counts, const double* mean, const double* cov) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    const size_t slot = seg_slot[g];
+    double mu[3], cv[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mu[j] = mean[slot * 3 + j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cv[j] = cov[slot * 6 + j];
+    finalize_slot(&slots[slot], counts[slot], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
 }
 
 // pcl::VoxelGrid centroid (src/slam/src/process.cc:68-73): mean of the cell's points, float64 sum in sorted order,
@@ -806,15 +881,26 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     if (rc != NDT_OK) return rc;
     HIP_TRY(w.flags2.ensure((size_t)nseg * 4 + 16));
     const uint32_t* segs = w.seg_start.as<uint32_t>();
-    if (sc.n_valid / nseg >= 24) {
+    uint32_t* seg_slot = w.segid.as<uint32_t>();        // free again once k_seg_starts has run; nseg <= n_valid entries
+    const bool wide = sc.n_valid / nseg >= 24;
+    const uint32_t big = wide ? 2048u : 512u;           // at most 32 / 64 trips of a group's loop
+    const size_t big_ub = sc.n_valid / big;              // no more segments than this can be longer than `big`
+    HIP_TRY(w.big_pos.ensure((size_t)nseg * 4)); HIP_TRY(w.big_list.ensure(big_ub * 4 + 16)); HIP_TRY(w.big_sums.ensure(big_ub * 9 * 8 + 16));
+    uint32_t* big_count = (uint32_t*)(w.misc.as<int32_t>() + 12);
+    k_big_list<<<(nseg + 255) / 256, 256, 0, s>>>(segs, nseg, big, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
+    if (big_ub)
+        k_big_sums<<<(unsigned)big_ub, BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, sc.sorted_keys, segs, w.gx.as<float>(), w.gy.as<float>(),
+                                                           w.gz.as<float>(), sc.km, cfg, w.big_sums.as<double>());
+    if (wide) {
         const unsigned nbs = (unsigned)(((size_t)nseg * 64 + 255) / 256);
-        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.slots, m.keys,
-                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>());
+        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.keys,
+                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>(), seg_slot, w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
     } else {
         const unsigned nbs = (unsigned)(((size_t)nseg * 8 + 255) / 256);
-        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.slots, m.keys,
-                                               m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>());
+        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.keys,
+                                               m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>(), seg_slot, w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
     }
+    k_finalize_segments<<<(nseg + 255) / 256, 256, 0, s>>>(seg_slot, nseg, cfg, m.slots, m.counts, m.mean, m.cov);
     HIP_TRY(hipGetLastError());
     return finish_entries(m, w, sc.sorted_keys, segs, nullptr, nseg, sc.km, s, err);
 }

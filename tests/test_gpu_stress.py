@@ -95,3 +95,40 @@ def test_linked_and_hashed_nearby7_agree_bit_for_bit(monkeypatch):
     assert np.array_equal(ka, kb) and np.array_equal(ma, mb)
     assert np.array_equal(ea["H"], eb["H"]) and np.array_equal(ea["b"], eb["b"]) and ea["n_effective"] == eb["n_effective"]
     assert np.array_equal(ra["T"], rb["T"]) and ra["iterations"] == rb["iterations"]
+
+
+def test_two_handles_on_two_host_threads_are_independent():
+    """SURVEY.md §8(b) threading: a handle is not thread-safe, distinct handles are independent (one HIP stream each).
+    Two host threads each drive their own handle through map build, merges, aligns and batches at the same time; every
+    result must equal, bit for bit, what the same calls give when the threads run one after the other."""
+    import threading
+
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    cfgs = [synth.make_config(0), synth.make_config(1)]
+
+    def job(c, out):
+        n = la.NDT(max_iterations=12, eps=1e-4)
+        res = []
+        for rep in range(6):
+            n.set_target(c["map"]); n.set_source(c["scan"])
+            res.append(n.align(c["guess"]))
+            n.add_target(c["scan"], res[-1]["T"])
+            res.append(n.align(c["guess"]))
+            res += n.align_batch([c["scan"][::2], c["scan"][1::2]], [c["guess"], c["T_true"], c["guess"]], [0, 1, 1])
+        out.append(res); n.close()
+
+    serial = [[], []]
+    for c, out in zip(cfgs, serial):
+        job(c, out)
+    conc = [[], []]
+    th = [threading.Thread(target=job, args=(c, out)) for c, out in zip(cfgs, conc)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for a, b in zip(serial, conc):
+        assert len(a) == len(b) == 1 and len(a[0]) == len(b[0]) == 6 * 5
+        for ra, rb in zip(a[0], b[0]):
+            assert ra.get("status", 0) == rb.get("status", 0) == 0 and ra["iterations"] == rb["iterations"]
+            assert np.array_equal(ra["T"], rb["T"]) and np.array_equal(ra["H"], rb["H"]) and np.array_equal(ra["b"], rb["b"])
