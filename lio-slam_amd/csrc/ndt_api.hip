@@ -53,8 +53,10 @@ struct ndt_handle {
     DevBuf sx, sy, sz, sraw;
     size_t n_src = 0;
     bool have_source = false;
-    DevBuf partials, cell_keys, cell_mask, pcl_partials;
+    DevBuf partials, partials2, cell_keys, cell_mask, pcl_partials;
     GnState* d_state = nullptr;
+    GnState* d_state2 = nullptr;               // the chained loop ping-pongs between the two; d_state always names the current one
+    bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
     std::string err;
     int last_radix_passes = 0;
@@ -121,8 +123,10 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
     if (!h) return nullptr;
     h->cfg = *cfg;
     h->use_links = getenv("NDT_NO_LINKS") ? 0 : 1;
+    h->use_chain = getenv("NDT_NO_CHAIN") == nullptr;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
+        hipMalloc((void**)&h->d_state2, sizeof(GnState)) != hipSuccess ||
         hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
         ndt_destroy(h);
         return nullptr;
@@ -137,11 +141,12 @@ void ndt_destroy(ndt_handle* h) {
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     map_free(h->map);
     h->work.release();
-    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->cell_keys, &h->cell_mask, &h->comm_rows, &h->braw, &h->bx, &h->by, &h->bz,
+    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->partials2, &h->cell_keys, &h->cell_mask, &h->comm_rows, &h->braw, &h->bx, &h->by, &h->bz,
                       &h->boff, &h->bpair, &h->bstates, &h->bpartials, &h->bdone};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_state2) (void)hipFree(h->d_state2);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -193,6 +198,7 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
         H_TRY(unpack_points_soa(h->sraw.p, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
     }
     H_TRY(h->partials.ensure((size_t)residual_grid(n) * ACC_N * sizeof(double)));
+    H_TRY(h->partials2.ensure((size_t)residual_grid(n) * ACC_N * sizeof(double)));
     H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
     h->n_src = n;
     h->have_source = true;
@@ -218,6 +224,7 @@ int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t 
     H_TRY(hipStreamSynchronize(h->stream));        // the only wait after the bounding box: the caller's buffer is free, n is known
     const size_t n_out = n32;
     H_TRY(h->partials.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
+    H_TRY(h->partials2.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
     h->n_src = n_out;
     h->have_source = true;
     return NDT_OK;
@@ -386,11 +393,28 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     const int max_it = h->cfg.max_iterations;
     // With eps == 0 the loop cannot stop early: queue everything and look once.
     const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
+    const bool chained = h->use_chain && !h->comm && !h->prof && h->n_src > 0;     // (profiling times the residual launches alone)
+    const EvalParams ep = eval_params(h);
+    const SolveParams sp = solve_params(h);
     int queued = 0;
     while (queued < max_it) {
         const int m = std::min(chunk, max_it - queued);
-        for (int i = 0; i < m; ++i)
-            if ((rc = queue_pass(h, 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
+        if (chained) {
+            // m iterations = m chained launches (launch i carries the step of launch i - 1) + the last step on its own
+            const int grid = residual_grid(h->n_src);
+            for (int i = 0; i < m; ++i) {
+                launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
+                                      (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, h->partials2.as<double>(), i ? grid : 0, sp, ep,
+                                      h->partials.as<double>(), grid, h->use_links, h->stream);
+                std::swap(h->d_state, h->d_state2);               // the launch published the state it used in st_out
+                std::swap(h->partials, h->partials2);             // partials2 = the rows just written
+            }
+            launch_reduce_solve(h->partials2.as<double>(), grid, h->d_state, sp, 1, 0, h->stream);
+            H_TRY(hipGetLastError());
+        } else {
+            for (int i = 0; i < m; ++i)
+                if ((rc = queue_pass(h, 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
+        }
         queued += m;
         H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));

@@ -269,6 +269,57 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
+// Chained form for the single-scan Gauss-Newton loop: every block first redoes, redundantly and with identical bits,
+// what k_reduce_solve would have done with the PREVIOUS launch's rows (fixed-order sum + step, state ping-ponged
+// between st_in and st_out; block 0 publishes st_out), then runs the residual pass at the new pose.  One launch per
+// iteration instead of two: the 4 us one-block kernel, its launch gap and its end-of-kernel write-back leave the
+// critical path; the price is ~60 KB of L2 reads and one serial solve per block.  n_prev = 0: no pending step.
+__device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp);
+__device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
+
+template <int K, bool LINKED>
+__global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __restrict__ xs, const float* __restrict__ ys,
+                                                                const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
+                                                                const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st_in,
+                                                                GnState* __restrict__ st_out, const double* __restrict__ prev_partials, int n_prev,
+                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials) {
+    static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
+    constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
+    __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
+    __shared__ GnState sst;
+    int i = blockIdx.x * RES1_THREADS + threadIdx.x;
+    float xf = 0.f, yf = 0.f, zf = 0.f;
+    if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    if (threadIdx.x < ST_WORDS) ((double*)&sst)[threadIdx.x] = ((const double*)st_in)[threadIdx.x];
+    if (n_prev > 0) reduce_rows32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
+    else __syncthreads();
+    if (n_prev > 0 && threadIdx.x == 0 && !sst.done) {
+        double acc0[ACC_N];
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) { acc0[j] = sm[0][j]; sst.acc[j] = acc0[j]; }
+        gn_step(&sst, acc0, sp);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < ST_WORDS) ((double*)st_out)[threadIdx.x] = ((const double*)&sst)[threadIdx.x];
+    if (sst.done) return;
+    Pose P;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) P.R[j] = sst.R[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P.t[j] = sst.t[j];
+    double acc[ACC_N];
+#pragma unroll
+    for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
+    while (i < n) {
+        int64_t ck;
+        if (LINKED) point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        else point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+        i += gridDim.x * RES1_THREADS;
+        if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    }
+    block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
+}
+
 // A batched residual launch can carry the reduction + Gauss-Newton step of ANOTHER group of pairs (whose residual rows the
 // previous launch wrote): a few extra blocks at the front of the grid.  The latency-bound step then runs underneath the
 // residual blocks instead of as a launch of its own with the GPU idle around it.
@@ -372,6 +423,15 @@ void launch_residual(const float* x, const float* y, const float* z, int n, cons
         if (linked) { if (keys_out) LAUNCH(7, true, true); else LAUNCH(7, false, true); }
         else { if (keys_out) LAUNCH(7, true, false); else LAUNCH(7, false, false); }
     } else { if (keys_out) LAUNCH(1, true, false); else LAUNCH(1, false, false); }
+#undef LAUNCH
+}
+
+void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
+                           const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
+                           const EvalParams& ep, double* partials, int grid, int linked, hipStream_t s) {
+#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials)
+    if (ep.nearby == 7) { if (linked) LAUNCH(7, true); else LAUNCH(7, false); }
+    else LAUNCH(1, false);
 #undef LAUNCH
 }
 
@@ -480,6 +540,34 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
     __syncthreads();
 #pragma unroll
     for (int o = RG / 2; o >= 1; o >>= 1) {
+        if (r < o) sm[r][c] += sm[r + o][c];
+        __syncthreads();
+    }
+}
+
+// reduce_rows<32> on a 512-thread block, same bits: thread (r, c) keeps the sums of row groups r and r + 16 apart and
+// adds them as the tree's first level would (a group's running sum starts at +0 and can never become -0, so the
+// zero padding the 1024-thread form adds is immaterial).
+__device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]) {
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    double va = 0.0, vb = 0.0;
+    for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 32 * u, j = i + 16;
+            x[u] = i < n_partials ? partials[(size_t)i * ACC_N + c] : 0.0;
+            y[u] = j < n_partials ? partials[(size_t)j * ACC_N + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) va += x[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vb += y[u];
+    }
+    sm[r][c] = va + vb;
+    __syncthreads();
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
         if (r < o) sm[r][c] += sm[r + o][c];
         __syncthreads();
     }

@@ -132,3 +132,41 @@ def test_two_handles_on_two_host_threads_are_independent():
         for ra, rb in zip(a[0], b[0]):
             assert ra.get("status", 0) == rb.get("status", 0) == 0 and ra["iterations"] == rb["iterations"]
             assert np.array_equal(ra["T"], rb["T"]) and np.array_equal(ra["H"], rb["H"]) and np.array_equal(ra["b"], rb["b"])
+
+
+def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
+    """The single-scan loop runs one launch per iteration (the previous iteration's reduction + step in every block's
+    prologue); NDT_NO_CHAIN=1 runs residual and reduce/solve as two launches.  Same sums in the same order, same step:
+    identical bits, for a loop that stops early (eps), one that runs to the cap, one that fails, and the 2 M-point grid
+    cap (2048 blocks, several points per lane)."""
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    c = synth.make_config(1, small=True)
+    rng = np.random.default_rng(3)
+    far = c["guess"].copy(); far[:3, 3] += [300.0, 0, 0]                      # no voxel in reach: too few residuals
+    big = np.concatenate([c["scan"] + rng.normal(0, 0.01, c["scan"].shape).astype(np.float32) for _ in range(70)])   # > 2048 x 512 points
+    res = []
+    for no_chain in (False, True):
+        if no_chain:
+            monkeypatch.setenv("NDT_NO_CHAIN", "1")
+        out = []
+        for cfg in (dict(max_iterations=35, eps=1e-2), dict(max_iterations=7, eps=0.0), dict(max_iterations=30, eps=1e-6, nearby=1),
+                    dict(max_iterations=9, eps=1e-3, final_eval=0)):
+            n = la.NDT(**cfg)
+            n.set_target(c["map"]); n.set_source(c["scan"])
+            out.append(n.align(c["guess"]))
+            out.append(n.align(c["T_true"]))
+            bad = n.align(far, check=False)
+            assert bad["rc"] < 0
+            out.append(bad)
+            n.set_source(big)
+            out.append(n.align(c["guess"]))
+            n.close()
+        res.append(out)
+    assert len(big) > 2048 * 512
+    for a, b in zip(*res):
+        assert a["iterations"] == b["iterations"] and a["converged"] == b["converged"]
+        for k in ("T", "H", "b"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert a["chi2"] == b["chi2"] and a["n_effective"] == b["n_effective"] and a["last_dx_norm"] == b["last_dx_norm"]
+    assert res[0][0]["iterations"] < 35 and res[0][4]["iterations"] == 7
