@@ -35,12 +35,12 @@ def algorithmic_bytes_per_point(k, h):
     return 12.0 + 8.0 * k + 40.0 * h
 
 
-def measured_traffic(kernel, points_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic_r01.json); None when
-    the file holds no measurement of a launch of this size."""
+def measured_traffic(kernel, points_per_launch, field="bytes_per_launch"):
+    """HBM bytes per launch of `kernel` (or its L2 hit rate) from the committed rocprofv3 PMC passes
+    (profiles/traffic_r01.json); None when the file holds no measurement of a launch of this size."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        return d[kernel]["bytes_per_launch"] if d[kernel]["points_per_launch"] == int(points_per_launch) else None
+        return d[kernel][field] if d[kernel]["points_per_launch"] == int(points_per_launch) else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -192,6 +192,8 @@ def main():
                   "scans_per_s": reps1 / el1, "source_points": int(n1),
                   "final_pose_error_m": float(np.linalg.norm((np.linalg.inv(w["T_true"]) @ r1["T"])[:3, 3])),
                   "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
+                               "traffic": measured_traffic(f"k_residual<{a.nearby}>", n1),
+                               "l2_hit_rate": measured_traffic(f"k_residual<{a.nearby}>", n1, "l2_hit_rate"),
                                "kernel": f"k_residual<{a.nearby}>", "kernel_avg_us": k1, "points_per_launch": int(n1),
                                "hits_per_point": h1, "bytes_per_point": algorithmic_bytes_per_point(a.nearby, h1)}}
 
@@ -302,8 +304,8 @@ def main():
         "scans_per_s": a.steps * (a.batch * world if a.mode == "replay" else 1) / el,
         "map_build_ms": build_ms, "keyframe_merge_ms": merge_ms,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(kname, ppl),
-                     "traffic_source": "profiles/traffic_r01.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, same workload)",
+                     "traffic": measured_traffic(kname, ppl), "l2_hit_rate": measured_traffic(kname, ppl, "l2_hit_rate"),
+                     "traffic_source": "profiles/traffic_r01.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE and TCC_HIT / TCC_MISS, separate passes, same workload)",
                      "kernel": kname, "kernel_avg_us": k_us, "bytes_per_point": bpp, "hits_per_point": h,
                      "points_per_launch": int(ppl),
                      "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"},

@@ -393,7 +393,9 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     const int max_it = h->cfg.max_iterations;
     // With eps == 0 the loop cannot stop early: queue everything and look once.
     const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
-    const bool chained = h->use_chain && !h->comm && !h->prof && h->n_src > 0;     // (profiling times the residual launches alone)
+    // (profiling times the residual launches alone; every block re-reads all rows of the previous launch, which only pays
+    // while there are few: a 2 M-point source has 2048 rows = 512 KB per block)
+    const bool chained = h->use_chain && !h->comm && !h->prof && h->n_src > 0 && residual_grid(h->n_src) <= 512;
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     int queued = 0;

@@ -137,14 +137,15 @@ def test_two_handles_on_two_host_threads_are_independent():
 def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
     """The single-scan loop runs one launch per iteration (the previous iteration's reduction + step in every block's
     prologue); NDT_NO_CHAIN=1 runs residual and reduce/solve as two launches.  Same sums in the same order, same step:
-    identical bits, for a loop that stops early (eps), one that runs to the cap, one that fails, and the 2 M-point grid
-    cap (2048 blocks, several points per lane)."""
+    identical bits, for a loop that stops early (eps), one that runs to the cap, one that fails, a source of ~400 rows
+    (more than one 256-row trip of the prologue's sum) and one above the 512-row limit of the chained form."""
     import lio_slam_amd as la
     from lio_slam_amd import synth
     c = synth.make_config(1, small=True)
     rng = np.random.default_rng(3)
     far = c["guess"].copy(); far[:3, 3] += [300.0, 0, 0]                      # no voxel in reach: too few residuals
-    big = np.concatenate([c["scan"] + rng.normal(0, 0.01, c["scan"].shape).astype(np.float32) for _ in range(70)])   # > 2048 x 512 points
+    big = np.concatenate([c["scan"] + rng.normal(0, 0.01, c["scan"].shape).astype(np.float32) for _ in range(40)])
+    mid = big[: 400 * 512 - 77]
     res = []
     for no_chain in (False, True):
         if no_chain:
@@ -159,14 +160,15 @@ def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
             bad = n.align(far, check=False)
             assert bad["rc"] < 0
             out.append(bad)
-            n.set_source(big)
-            out.append(n.align(c["guess"]))
+            for src in (mid, big):
+                n.set_source(src)
+                out.append(n.align(c["guess"]))
             n.close()
         res.append(out)
-    assert len(big) > 2048 * 512
+    assert 256 * 512 < len(mid) <= 512 * 512 < len(big)
     for a, b in zip(*res):
         assert a["iterations"] == b["iterations"] and a["converged"] == b["converged"]
         for k in ("T", "H", "b"):
             assert np.array_equal(a[k], b[k], equal_nan=True), k
         assert a["chi2"] == b["chi2"] and a["n_effective"] == b["n_effective"] and a["last_dx_norm"] == b["last_dx_norm"]
-    assert res[0][0]["iterations"] < 35 and res[0][4]["iterations"] == 7
+    assert res[0][0]["iterations"] < 35 and res[0][5]["iterations"] == 7

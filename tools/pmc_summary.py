@@ -3,7 +3,7 @@ import csv, glob, sys, collections
 tag = sys.argv[1]
 def short(n): return n.split("(")[0].replace("void ", "")[:28]
 for f in glob.glob(f"gpurun_out/{tag}_trace/*/*kernel_stats.csv"):
-    for r in list(csv.DictReader(open(f)))[:4]:
+    for r in list(csv.DictReader(open(f)))[:6]:
         print(f"{short(r['Name']):30s} calls {r['Calls']:>6s} avg_ns {float(r['AverageNs']):10.0f} min {r['MinNs']} max {r['MaxNs']}")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(f"gpurun_out/{tag}_pmc*/*/*counter_collection.csv")):
