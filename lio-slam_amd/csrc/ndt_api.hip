@@ -757,6 +757,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
         flush();
         queued += m;
         H_TRY(hipGetLastError());
+        if (queued >= max_it) break;                  // nothing left to decide: the state read-back below is the synchronisation
         int32_t n_done = 0;
         H_TRY(hipMemcpyAsync(&n_done, h->bdone.p, 4, hipMemcpyDeviceToHost, s));
         H_TRY(hipStreamSynchronize(s));
