@@ -101,3 +101,66 @@ def test_random_scene_and_config(seed):
                 dt, dr = pose_error(rb[p]["T"], rp["T"])
                 assert dt < 1e-4 and dr < 1e-5 and rb[p]["iterations"] == rp["iterations"], (p, dt, dr)
     n.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_downsample(seed):
+    """pcl::VoxelGrid on the device against the oracle: random leaf sizes and extrinsics, non-finite points, negative
+    coordinates, from one point per cell to hundreds.  Same cells in the same (PCL index) order; centroids are float64
+    sums in a different order, rounded once to float32: equal to 1 ulp, and almost always bit for bit."""
+    import lio_slam_amd as la
+    from oracle.oracle import voxel_downsample
+    rng = np.random.default_rng(2000 + seed)
+    leaf = float(rng.choice([0.1, 0.2, 0.5, 1.0, 2.0]))
+    pts, origin = _scene(rng, int(rng.integers(2000, 60000)), extent=float(rng.uniform(20, 200)) * leaf)
+    pts = rng.permutation(pts - origin.astype(np.float32))           # a scan in its sensor frame, both signs
+    bad = rng.choice(len(pts), 30, replace=False)
+    pts[bad[:20], rng.integers(0, 3, 20)] = np.nan
+    pts[bad[20:], rng.integers(0, 3, 10)] = np.inf
+    T = None if seed % 3 == 0 else _se3(rng, 1.5, 0.4)
+    n = la.NDT()
+    n.set_source_downsampled(pts, leaf, T)
+    g = n.get_source()
+    o = voxel_downsample(pts, leaf, T)
+    assert g.shape == o.shape and len(o) > 100
+    inv = np.float32(1.0) / np.float32(leaf)
+    assert np.array_equal(np.floor(g * inv).astype(np.int32), np.floor(o * inv).astype(np.int32))
+    assert np.max(np.abs(g.astype(np.float64) - o) / np.maximum(np.abs(o), 1.0)) < 2.5e-7
+    assert np.mean(np.all(g == o, axis=1)) > 0.98
+    n.set_source_downsampled(pts[:1], leaf, T)                        # one point: its own centroid
+    assert n.source_size() == (1 if np.isfinite(pts[0]).all() else 0)
+    n.close()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_pcl_mode(seed):
+    """PCL compatibility mode against the oracle's PCL-literal restatement on random scenes: resolutions, outlier ratios,
+    step sizes, both forms of the angular Hessian row, merges before the evaluation, non-finite source points."""
+    import lio_slam_amd as la
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(3000 + seed)
+    res = float(rng.choice([0.5, 1.0, 2.0]))
+    cfg = dict(resolution=res, max_iterations=int(rng.integers(2, 12)), eps=float(rng.choice([1e-2, 1e-4, 1e-6])))
+    prm = dict(outlier_ratio=float(rng.choice([0.3, 0.55, 0.8])), step_size=float(rng.choice([0.05, 0.1, 0.5])) * res,
+               hessian_d1_as_pcl=int(rng.integers(0, 2)))
+    pts, origin = _scene(rng, int(rng.integers(6000, 20000)), extent=float(rng.uniform(10, 25)) * res)
+    pts = rng.permutation(pts - origin.astype(np.float32))           # PCL mode works in the map frame: keep the angles' lever arm short
+    n = la.NDT(**cfg); o = Oracle(**cfg)
+    h = len(pts) // 2
+    n.set_target(pts[:h]); o.set_target(pts[:h]); n.add_target(pts[h:]); o.add_target(pts[h:])
+    T_true = _se3(rng, 1.0, 0.2)
+    sel = rng.choice(len(pts), int(rng.integers(800, 4000)), replace=False)
+    src = ((pts[sel].astype(np.float64) - T_true[:3, 3]) @ T_true[:3, :3]).astype(np.float32)
+    src[3] = np.nan; src[11, 2] = np.inf
+    guess = T_true @ _se3(rng, 0.1 * res, 0.01)
+    n.set_source(src); o.set_source(src)
+    p = la.pcl_vector_from_matrix(guess)
+    rn, ro = n.pcl_eval(p, **prm), o.pcl_eval(p, **prm)
+    assert rn["n_neighbours"] == ro["n_neighbours"] > 0
+    assert abs(rn["score"] - ro["score"]) <= 1e-6 * abs(ro["score"])
+    assert rel_err(rn["g"], ro["g"]) < 1e-6 and rel_err(rn["H"], ro["H"]) < 1e-6
+    ra, rb = n.pcl_align(guess, **prm), o.pcl_align(guess, **prm)
+    assert ra["rc"] == rb["rc"] == 0 and ra["iterations"] == rb["iterations"] and ra["evaluations"] == rb["evaluations"]
+    dt, dr = pose_error(ra["T"], rb["T"])
+    assert dt < 1e-6 and dr < 1e-7, (dt, dr)
+    n.close()
