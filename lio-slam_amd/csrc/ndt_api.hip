@@ -46,6 +46,9 @@ enum { NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
 struct ndt_handle {
     ndt_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};   // further launch lanes of a replay batch (independent pairs: no ordering between lanes)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int batch_lanes = 2;                       // NDT_BATCH_LANES=1..4 (A/B switch)
     VoxelMap map;
     MapWork work;
     MapBuildCfg build_cfg;      // parameters the resident map was built with
@@ -74,7 +77,7 @@ struct ndt_handle {
     DevBuf comm_rows;            // [2][ACC_N] doubles: all-reduce send / receive rows
     // offline replay batch
     DevBuf braw, bx, by, bz, boff, bpair, bstates, bpartials, bdone;
-    size_t b_group = 0;                        // pairs per launch group of the resident batch
+    size_t b_group = 0;                        // pairs per launch (one lane) of the resident batch
     std::vector<int64_t> b_offsets; int64_t b_max_pts = 0;
     size_t b_pairs = 0; int b_rows = 0; bool b_has_pair_scan = false; double b_points = 0;   // geometry of the resident batch
 };
@@ -124,7 +127,15 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
     h->cfg = *cfg;
     h->use_links = getenv("NDT_NO_LINKS") ? 0 : 1;
     h->use_chain = getenv("NDT_NO_CHAIN") == nullptr;
+    if (const char* e = getenv("NDT_BATCH_LANES")) h->batch_lanes = std::min(4, std::max(1, atoi(e)));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->lane_stream[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->lane_stream[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->lane_stream[2], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
         hipMalloc((void**)&h->d_state2, sizeof(GnState)) != hipSuccess ||
         hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
@@ -138,6 +149,7 @@ void ndt_destroy(ndt_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t ls : h->lane_stream) if (ls) (void)hipStreamSynchronize(ls);
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     map_free(h->map);
     h->work.release();
@@ -149,6 +161,9 @@ void ndt_destroy(ndt_handle* h) {
     if (h->d_state2) (void)hipFree(h->d_state2);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (hipStream_t ls : h->lane_stream) if (ls) (void)hipStreamDestroy(ls);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -705,17 +720,27 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     for (size_t p = 0; p < n_pairs; ++p) state_from_T(&st[p], guesses + 16 * p);
     H_TRY(h->bstates.ensure(n_pairs * sizeof(GnState)));
     H_TRY(hipMemcpyAsync(h->bstates.p, st.data(), n_pairs * sizeof(GnState), hipMemcpyHostToDevice, s));
-    // Launch groups: with eight pairs or more the batch goes in two launches per iteration, and each launch carries the
-    // reduction + Gauss-Newton step of the OTHER group's previous launch as a few extra blocks (launch_residual_batch's
-    // `carry`), so that the latency-bound step never has the GPU to itself.
-    const size_t CH = 32768;                  // gridDim.y limit is 65535
-    const size_t group = n_pairs >= 8 ? std::min(CH, (n_pairs + 1) / 2) : n_pairs;
-    const size_t n_groups = (n_pairs + group - 1) / group;
+    // Launch lanes.  The pairs are independent problems, so the batch is cut into (up to) two LANES, each on a HIP stream
+    // of its own with no ordering between them: one lane's blocks fill the tail of the other's residual launch, and its
+    // latency-bound reduce + Gauss-Newton kernel runs underneath the other's residual kernel instead of with the GPU to
+    // itself.  (More lanes bring nothing; see DESIGN.md §5 for what this replaced.)
+    const size_t CH = 32768;                  // pairs per launch: gridDim.y limit is 65535
+    struct Lane { hipStream_t s; size_t p0, np; };
+    const int n_lanes = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->batch_lanes, n_pairs / 2));
+    Lane lanes[4];
+    for (int l = 0; l < n_lanes; ++l) {
+        const size_t per = (n_pairs + n_lanes - 1) / n_lanes;
+        lanes[l].s = l ? h->lane_stream[l - 1] : s;
+        lanes[l].p0 = l * per; lanes[l].np = std::min(per, n_pairs - l * per);
+    }
+    const size_t group = std::min(CH, lanes[0].np);      // the largest launch: sizes the grid rows for all of them
     const int rows = residual_grid((size_t)max_pts, group);
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
     // no wait here: pair_scan (the caller's) and st stay alive until the loop's own synchronisation below
+    if (n_lanes > 1) H_TRY(hipEventRecord(h->ev_fork, s));
+    for (int l = 1; l < n_lanes; ++l) H_TRY(hipStreamWaitEvent(lanes[l].s, h->ev_fork, 0));
 
     h->b_pairs = n_pairs; h->b_rows = rows; h->b_has_pair_scan = pair_scan != nullptr; h->b_group = group;
     h->b_points = 0;
@@ -724,39 +749,32 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     const SolveParams sp = solve_params(h);
     GnState* dst = h->bstates.as<GnState>();
     const int32_t* dps = pair_scan ? h->bpair.as<int32_t>() : nullptr;
-    struct { bool has = false; size_t p0 = 0; int np = 0, do_solve = 0, force = 0; } pend;      // a group whose rows wait to be reduced
-    auto carried = [&]() {
-        CarriedReduce c;
-        c.partials = h->bpartials.as<double>() + pend.p0 * (size_t)rows * ACC_N; c.states = dst + pend.p0; c.n_done = h->bdone.as<int32_t>();
-        c.sp = sp; c.rows_per_pair = rows; c.n_pairs = pend.np; c.do_solve = pend.do_solve; c.force = pend.force;
-        return c;
-    };
-    auto flush = [&]() {      // the pending reduction as a launch of its own (before the host looks, or when there is one group only)
-        if (!pend.has) return;
-        launch_reduce_solve_batch(h->bpartials.as<double>() + pend.p0 * (size_t)rows * ACC_N, rows, dst + pend.p0, pend.np, sp, pend.do_solve,
-                                  pend.force, h->bdone.as<int32_t>(), s);
-        pend.has = false;
-    };
-    auto pass = [&](int do_solve, int force) {
-        for (size_t g = 0; g < n_groups; ++g) {
-            const size_t p0 = g * group;
-            const int np = (int)std::min(group, n_pairs - p0);
-            if (n_groups == 1) flush();           // a group's next residual needs its own step first
-            const CarriedReduce c = carried();
+    auto pass = [&](const Lane& L, int do_solve, int force) {
+        for (size_t p0 = L.p0; p0 < L.p0 + L.np; p0 += CH) {
+            const int np = (int)std::min(CH, L.p0 + L.np - p0);
             launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(), dps, h->map.keys,
-                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, h->use_links,
-                                  pend.has ? &c : nullptr, s);
-            pend.has = true; pend.p0 = p0; pend.np = np; pend.do_solve = do_solve; pend.force = force;
+                                  h->map.slots, (uint32_t)(h->map.cap - 1), dst, ep, h->bpartials.as<double>(), rows, (int)p0, np, force, h->use_links, L.s);
+            launch_reduce_solve_batch(h->bpartials.as<double>() + p0 * (size_t)rows * ACC_N, rows, dst + p0, np, sp, do_solve, force,
+                                      h->bdone.as<int32_t>(), L.s);
         }
+    };
+    // m passes on every lane (launches interleaved so that both streams fill early), then the lanes are joined on s
+    auto run = [&](int m, int do_solve, int force) -> hipError_t {
+        for (int i = 0; i < m; ++i)
+            for (int l = 0; l < n_lanes; ++l) pass(lanes[l], do_solve, force);
+        hipError_t e = hipGetLastError();
+        for (int l = 1; l < n_lanes && e == hipSuccess; ++l) {
+            e = hipEventRecord(h->ev_join[l - 1], lanes[l].s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, h->ev_join[l - 1], 0);
+        }
+        return e;
     };
     const int max_it = h->cfg.max_iterations;
     const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
     for (int queued = 0; queued < max_it;) {
         const int m = std::min(chunk, max_it - queued);
-        for (int i = 0; i < m; ++i) pass(1, 0);
-        flush();
+        H_TRY(run(m, 1, 0));
         queued += m;
-        H_TRY(hipGetLastError());
         if (queued >= max_it) break;                  // nothing left to decide: the state read-back below is the synchronisation
         int32_t n_done = 0;
         H_TRY(hipMemcpyAsync(&n_done, h->bdone.p, 4, hipMemcpyDeviceToHost, s));
@@ -767,9 +785,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
     H_TRY(hipMemcpyAsync(loop.data(), dst, n_pairs * sizeof(GnState), hipMemcpyDeviceToHost, s));
     H_TRY(hipStreamSynchronize(s));
     if (h->cfg.final_eval) {
-        pass(0, 1);
-        flush();
-        H_TRY(hipGetLastError());
+        H_TRY(run(1, 0, 1));
         H_TRY(hipMemcpyAsync(st.data(), dst, n_pairs * sizeof(GnState), hipMemcpyDeviceToHost, s));
         H_TRY(hipStreamSynchronize(s));
     } else st = loop;
@@ -868,7 +884,7 @@ int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, doub
     H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
-    // the launches the batched loop makes: one per group of pairs, here back to back and without the carried reductions
+    // the launches the batched loop makes (one per lane), here back to back on one stream
     const size_t group = h->b_group ? h->b_group : h->b_pairs, n_groups = (h->b_pairs + group - 1) / group;
     auto pass = [&]() {
         for (size_t g = 0; g < n_groups; ++g) {
@@ -876,7 +892,7 @@ int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, doub
             launch_residual_batch(h->bx.as<float>(), h->by.as<float>(), h->bz.as<float>(), h->boff.as<int64_t>(),
                                   h->b_has_pair_scan ? h->bpair.as<int32_t>() : nullptr, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
                                   h->bstates.as<GnState>(), ep, h->bpartials.as<double>(), h->b_rows, (int)p0, (int)std::min(group, h->b_pairs - p0), 1,
-                                  h->use_links, nullptr, h->stream);
+                                  h->use_links, h->stream);
         }
     };
     for (int i = 0; i < 3; ++i) pass();

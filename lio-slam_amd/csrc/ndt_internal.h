@@ -121,11 +121,8 @@ void launch_reduce_solve(const double* partials, int n_partials, GnState* st, co
                          int force, hipStream_t s);
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s);
 void launch_solve_only(GnState* st, const double* reduced, const SolveParams& sp, int do_solve, int force, hipStream_t s);
-// carry: reduction + Gauss-Newton step of another group of pairs (rows written by an earlier launch) to run as extra
-// blocks of this launch; nullptr = none.
-struct CarriedReduce { const double* partials; GnState* states; int32_t* n_done; SolveParams sp; int32_t rows_per_pair, n_pairs, do_solve, force; };
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
                            const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
-                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, const CarriedReduce* carry, hipStream_t s);
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, hipStream_t s);
 void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
                                int do_solve, int force, int32_t* n_done, hipStream_t s);

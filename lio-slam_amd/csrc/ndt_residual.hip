@@ -320,18 +320,6 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
 
-// A batched residual launch can carry the reduction + Gauss-Newton step of ANOTHER group of pairs (whose residual rows the
-// previous launch wrote): a few extra blocks at the front of the grid.  The latency-bound step then runs underneath the
-// residual blocks instead of as a launch of its own with the GPU idle around it.
-struct PiggyReduce {
-    const double* partials;   // rows of the carried group (nullptr: nothing carried)
-    GnState* states;
-    int32_t* n_done;
-    SolveParams sp;
-    int32_t rows_per_pair, n_pairs, do_solve, force;
-};
-__device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done);
-
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
 // pair's scan.  Scans are stored back to back in xs/ys/zs; pair p reads scan pair_scan[p] (or p) and its own GnState.
 template <int K, bool LINKED>
@@ -340,13 +328,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
                                                                 const int32_t* __restrict__ pair_scan, const int64_t* __restrict__ keys,
                                                                 const VoxSlot* __restrict__ slots, uint32_t mask,
                                                                 const GnState* __restrict__ states, EvalParams ep,
-                                                                double* __restrict__ partials, int rows_per_pair, int force, PiggyReduce pg, int pg_rows) {
-    if ((int)blockIdx.y < pg_rows) {          // the first pg_rows grid rows: one block per carried pair
-        const int cp = blockIdx.y * gridDim.x + blockIdx.x;
-        if (cp < pg.n_pairs) reduce_solve_pair(pg.partials + (size_t)cp * pg.rows_per_pair * ACC_N, pg.rows_per_pair, pg.states + cp, pg.sp, pg.do_solve, pg.force, pg.n_done);
-        return;
-    }
-    const int pair = blockIdx.y - pg_rows;
+                                                                double* __restrict__ partials, int rows_per_pair, int force) {
+    const int pair = blockIdx.y;
     const int scan = pair_scan ? pair_scan[pair] : pair;
     const int64_t lo = scan_off[scan], hi = scan_off[scan + 1];
     const GnState* st = states + pair;
@@ -629,22 +612,15 @@ __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const doubl
 
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,
                            const int64_t* keys, const VoxSlot* slots, uint32_t mask, const GnState* states, const EvalParams& ep,
-                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, const CarriedReduce* carry, hipStream_t s) {
-    PiggyReduce pg{};
-    int pg_rows = 0;
-    if (carry && carry->n_pairs > 0) {
-        pg.partials = carry->partials; pg.states = carry->states; pg.n_done = carry->n_done; pg.sp = carry->sp;
-        pg.rows_per_pair = carry->rows_per_pair; pg.n_pairs = carry->n_pairs; pg.do_solve = carry->do_solve; pg.force = carry->force;
-        pg_rows = (carry->n_pairs + rows_per_pair - 1) / rows_per_pair;
-    }
-    dim3 grid((unsigned)rows_per_pair, (unsigned)(n_pairs + pg_rows));
+                           double* partials, int rows_per_pair, int pair0, int n_pairs, int force, int linked, hipStream_t s) {
+    dim3 grid((unsigned)rows_per_pair, (unsigned)n_pairs);
     const int32_t* ps = pair_scan ? pair_scan + pair0 : nullptr;
     // without pair_scan pair p reads scan p, so the offsets are shifted together with the states
     const int64_t* so = pair_scan ? scan_off : scan_off + pair0;
     double* pp = partials + (size_t)pair0 * rows_per_pair * ACC_N;
-    if (ep.nearby == 7 && linked) k_residual_batch<7, true><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
-    else if (ep.nearby == 7) k_residual_batch<7, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
-    else k_residual_batch<1, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force, pg, pg_rows);
+    if (ep.nearby == 7 && linked) k_residual_batch<7, true><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    else if (ep.nearby == 7) k_residual_batch<7, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
+    else k_residual_batch<1, false><<<grid, RES_THREADS, 0, s>>>(x, y, z, so, ps, keys, slots, mask, states + pair0, ep, pp, rows_per_pair, force);
 }
 void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnState* states, int n_pairs, const SolveParams& sp,
                                int do_solve, int force, int32_t* n_done, hipStream_t s) {

@@ -1,5 +1,6 @@
 """Short profiling driver: configs[2] workload (cached by bench.py under /tmp), N aligns.  Used under rocprofv3."""
 import sys, os
+os.environ["NDT_BATCH_LANES"] = "1"   # one launch lane: kernels run alone, so the trace's durations are those of bench.py's HIP-event timing
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, lio_slam_amd as la
 n_align = int(sys.argv[1]) if len(sys.argv) > 1 else 20
