@@ -11,9 +11,9 @@ for _ in range(n_align):
     r = ndt.align(w["guess"])          # k_residual_chain x iterations + one k_reduce_solve
 for _ in range(n_align):
     ndt.eval(w["guess"]); ndt.eval(r["T"])     # k_residual (the pass bench.py times alone) + k_reduce_solve
-if len(sys.argv) > 2:      # also a few batched aligns (bench.py's default batch)
+if len(sys.argv) > 2:      # also a few batched aligns: one lane of bench.py's default batch (= the launches bench.py times)
     scans = [w[f"scan{j}"] for j in range(8)]
     ndt.set_batch_sources(scans)
     for _ in range(int(sys.argv[2])):
-        ndt.align_batch_resident([w[f"guess{p % 8}"] for p in range(bench.DEFAULT_BATCH)], [p % 8 for p in range(bench.DEFAULT_BATCH)])
+        ndt.align_batch_resident([w[f"guess{p % 8}"] for p in range(bench.DEFAULT_BATCH // 2)], [p % 8 for p in range(bench.DEFAULT_BATCH // 2)])
 print("done", r["iterations"], ndt.num_voxels())
