@@ -117,8 +117,8 @@ def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--iters", type=int, default=10, help="Gauss-Newton iterations per align (fixed)")
     ap.add_argument("--nearby", type=int, default=7)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="scan-to-map pairs aligned together per step (replay mode)")

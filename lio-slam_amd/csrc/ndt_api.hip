@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #define SYNC_CHUNK 4
@@ -28,18 +29,22 @@ static struct {
     pfn_ncclCommDestroy destroy;
 } g_rccl;
 static bool rccl_load() {
-    if (g_rccl.lib) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* nm : names) {
-        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.lib) break;
-    }
-    if (!g_rccl.lib) return false;
-    g_rccl.get_id = (pfn_ncclGetUniqueId)dlsym(g_rccl.lib, "ncclGetUniqueId");
-    g_rccl.init_rank = (pfn_ncclCommInitRank)dlsym(g_rccl.lib, "ncclCommInitRank");
-    g_rccl.all_reduce = (pfn_ncclAllReduce)dlsym(g_rccl.lib, "ncclAllReduce");
-    g_rccl.destroy = (pfn_ncclCommDestroy)dlsym(g_rccl.lib, "ncclCommDestroy");
-    return g_rccl.get_id && g_rccl.init_rank && g_rccl.all_reduce && g_rccl.destroy;
+    static std::once_flag once;        // handles on several host threads may reach this together
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        void* lib = nullptr;
+        for (const char* nm : names) {
+            lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        g_rccl.get_id = (pfn_ncclGetUniqueId)dlsym(lib, "ncclGetUniqueId");
+        g_rccl.init_rank = (pfn_ncclCommInitRank)dlsym(lib, "ncclCommInitRank");
+        g_rccl.all_reduce = (pfn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
+        g_rccl.destroy = (pfn_ncclCommDestroy)dlsym(lib, "ncclCommDestroy");
+        g_rccl.lib = lib;
+    });
+    return g_rccl.lib && g_rccl.get_id && g_rccl.init_rank && g_rccl.all_reduce && g_rccl.destroy;
 }
 enum { NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
 
@@ -153,7 +158,7 @@ void ndt_destroy(ndt_handle* h) {
     if (h->comm && g_rccl.destroy) g_rccl.destroy(h->comm);
     map_free(h->map);
     h->work.release();
-    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->partials2, &h->cell_keys, &h->cell_mask, &h->comm_rows, &h->braw, &h->bx, &h->by, &h->bz,
+    DevBuf* bufs[] = {&h->sx, &h->sy, &h->sz, &h->sraw, &h->partials, &h->partials2, &h->cell_keys, &h->cell_mask, &h->pcl_partials, &h->comm_rows, &h->braw, &h->bx, &h->by, &h->bz,
                       &h->boff, &h->bpair, &h->bstates, &h->bpartials, &h->bdone};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -226,6 +231,7 @@ int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t 
     if (!h) return NDT_ERR_INVALID_ARG;
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     if (!(leaf > 0.f) || !isfinite(leaf)) { h->err = "leaf size must be positive"; return NDT_ERR_INVALID_ARG; }
+    if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
     KeyParams kp;
     kp.inv_leaf_f32 = 1.0f / leaf; kp.inv_res_d = (double)kp.inv_leaf_f32; kp.res_d = (double)leaf; kp.key_rule = NDT_KEY_FLOOR_F32;

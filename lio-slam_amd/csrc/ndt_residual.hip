@@ -15,6 +15,8 @@
 // never returns to the host.
 // Bound: HBM/L2 gather (12 + 8K + 40h algorithmic bytes per point); no MFMA.
 #include "ndt_internal.h"
+
+#include <atomic>
 #include "ndt_kernels.h"
 
 #define RES_THREADS 256    // batched launches: several blocks per CU overlap their tails
@@ -373,8 +375,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 // Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
 // the whole launch is small (latency-bound: every wave should be resident at once); up to 8 points per lane once
 // there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
-static int g_cu_count = 256;
-void residual_set_cu_count(int n) { if (n > 0) g_cu_count = n; }
+static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on several host threads
+void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
 int residual_grid(size_t n, size_t problems) {
     if (problems <= 1) {                              // k_residual: 512-thread blocks, one point per lane up to 2048 blocks
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
@@ -384,7 +386,7 @@ int residual_grid(size_t n, size_t problems) {
     // grid is chosen against the tail effect: time ~ (rounds of resident blocks) x (points per lane + 2 for the block's
     // reduction and row store), ties to the longer lane loop: 8 pairs of 118 k points run as 464 blocks of 8 points per
     // lane (one round) rather than 528 blocks of 7 (two rounds); large batches settle on 8 (measured: DESIGN.md §5).
-    const size_t resident = (size_t)2 * (size_t)g_cu_count;
+    const size_t resident = (size_t)2 * (size_t)g_cu_count.load(std::memory_order_relaxed);
     size_t best_ppt = 1, best_cost = ~(size_t)0;
     for (size_t ppt = 8; ppt >= 1; --ppt) {
         const size_t rows = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
