@@ -261,6 +261,25 @@ int ndt_comm_unique_id(char id_out[128]);
 int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]);
 int ndt_comm_destroy(ndt_handle* h);
 
+/* Several GPUs in ONE process (SURVEY.md §8(b) "multi-GPU: ndt_create_group(n_dev, dev_ids)"; the replay half of
+ * §8(e)): a group is one member handle per entry of dev_ids (cfg->device is ignored; a device may be listed more than
+ * once), every member with a replica of the map.  The group calls fan out to the members on one host thread each:
+ * set / add target builds the same map everywhere, align_batch deals the pairs to the members in contiguous shares
+ * (each member uploads only the scans its pairs use) and gathers the results in pair order; no collective.  Per-pair
+ * results are those of ndt_align_batch on one handle, up to the summation order of a differently sized batch.
+ * ndt_group_handle gives a member for per-device calls (ndt_align, ndt_export_voxels, ...).  A sharded source
+ * (ndt_comm_*) stays one process per GPU.  No counterpart in the reference, which has one CPU thread. */
+typedef struct ndt_group ndt_group;
+ndt_group* ndt_create_group(const ndt_config* cfg, int n_dev, const int* dev_ids);
+void ndt_destroy_group(ndt_group* g);
+int ndt_group_size(const ndt_group* g);
+ndt_handle* ndt_group_handle(ndt_group* g, int member);
+int ndt_group_set_target(ndt_group* g, const void* pts, size_t n, size_t stride_bytes);
+int ndt_group_add_target(ndt_group* g, const void* pts, size_t n, size_t stride_bytes, const double T[16]);
+int ndt_group_align_batch(ndt_group* g, const void* pts, size_t stride_bytes, const int64_t* scan_offsets, size_t n_scans,
+                          const int32_t* pair_scan, size_t n_pairs, const double* guesses, ndt_result* results);
+const char* ndt_group_last_error(const ndt_group* g);
+
 /* Device-time accounting for benchmarks: total microseconds and launches of the
  * residual kernel since the last reset, measured with HIP events on the
  * handle's own stream (enable with ndt_profile(h, 1)). */

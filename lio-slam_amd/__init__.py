@@ -26,6 +26,8 @@ ABI_SYMBOLS = [
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version",
+    "ndt_create_group", "ndt_destroy_group", "ndt_group_size", "ndt_group_handle", "ndt_group_set_target", "ndt_group_add_target",
+    "ndt_group_align_batch", "ndt_group_last_error",
 ]
 
 
@@ -117,6 +119,18 @@ def lib():
     L.ndt_align_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     L.ndt_set_batch_sources.argtypes = [vp, vp, sz, vp, sz]
     L.ndt_align_batch_resident.argtypes = [vp, vp, sz, vp, vp]
+    L.ndt_create_group.restype = vp
+    L.ndt_create_group.argtypes = [vp, C.c_int, vp]
+    L.ndt_destroy_group.argtypes = [vp]
+    L.ndt_destroy_group.restype = None
+    L.ndt_group_size.argtypes = [vp]
+    L.ndt_group_handle.restype = vp
+    L.ndt_group_handle.argtypes = [vp, C.c_int]
+    L.ndt_group_set_target.argtypes = [vp, vp, sz, sz]
+    L.ndt_group_add_target.argtypes = [vp, vp, sz, sz, vp]
+    L.ndt_group_align_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    L.ndt_group_last_error.restype = C.c_char_p
+    L.ndt_group_last_error.argtypes = [vp]
     L.ndt_comm_unique_id.argtypes = [vp]
     L.ndt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ndt_comm_destroy.argtypes = [vp]
@@ -166,6 +180,72 @@ def _points(pts):
     return a, a.ctypes.data, a.shape[0], a.shape[1] * 4
 
 
+def _unpack_results(res):
+    """structured ndt_result array -> list of result dicts (vectorised: a replay loop in Python would otherwise spend
+    more time here than the GPU spends aligning)"""
+    n_pairs = len(res)
+    T = res["T"].reshape(n_pairs, 4, 4).transpose(0, 2, 1)
+    H = res["H"].reshape(n_pairs, 6, 6)
+    return [dict(rc=int(st), status=int(st), T=T[i], H=H[i], b=res["b"][i], chi2=float(res["chi2"][i]),
+                 n_effective=int(res["n_effective"][i]), iterations=int(res["iterations"][i]),
+                 converged=bool(res["converged"][i]), last_dx_norm=float(res["last_dx_norm"][i]))
+            for i, st in enumerate(res["status"])]
+
+
+class NDTGroup:
+    """Several GPUs in one process (ndt_create_group): one member engine per entry of `devices`, map replicas, a replay
+    batch dealt to the members in contiguous shares.  member(i) is a borrowed NDT for per-device calls."""
+
+    def __init__(self, devices, **cfg):
+        self.cfg = default_config(**cfg)
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._g = lib().ndt_create_group(C.byref(self.cfg), len(devices), ids)
+        if not self._g:
+            raise NdtError(-4, "ndt_create_group failed (device not visible, or bad config)")
+
+    def close(self):
+        if getattr(self, "_g", None):
+            lib().ndt_destroy_group(self._g)
+            self._g = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NdtError(rc, lib().ndt_group_last_error(self._g).decode())
+
+    def __len__(self): return lib().ndt_group_size(self._g)
+
+    def member(self, i):
+        h = lib().ndt_group_handle(self._g, int(i))
+        if not h:
+            raise IndexError(i)
+        n = NDT.__new__(NDT)
+        n.cfg, n._h, n.final, n._borrowed = self.cfg, h, None, True
+        return n
+
+    def set_target(self, pts):
+        keep, p, n, s = _points(pts)
+        self._chk(lib().ndt_group_set_target(self._g, p, n, s))
+
+    def add_target(self, pts, T=None):
+        keep, p, n, s = _points(pts)
+        t = None if T is None else _T(T)
+        self._chk(lib().ndt_group_add_target(self._g, p, n, s, None if t is None else t.ctypes.data))
+
+    def align_batch(self, scans, guesses, pair_scan=None):
+        scans = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)[:, :3]) for a in scans]
+        pts = np.ascontiguousarray(np.concatenate(scans))
+        off = np.zeros(len(scans) + 1, np.int64); off[1:] = np.cumsum([len(a) for a in scans])
+        G = np.asarray(guesses, dtype=np.float64)
+        g = np.ascontiguousarray(G.transpose(0, 2, 1)).reshape(len(G), 16)
+        ps = None if pair_scan is None else np.ascontiguousarray(pair_scan, dtype=np.int32)
+        res = np.zeros(len(g), RESULT_DTYPE)
+        self._chk(lib().ndt_group_align_batch(self._g, pts.ctypes.data, 12, off.ctypes.data, len(scans), None if ps is None else ps.ctypes.data,
+                                              len(g), g.ctypes.data, res.ctypes.data))
+        return _unpack_results(res)
+
+
 class NDT:
     """Mirror of the reference's NDT member: set target, set source, align from a guess, read pose + Hessian.
 
@@ -182,7 +262,8 @@ class NDT:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().ndt_destroy(self._h)
+            if not getattr(self, "_borrowed", False):       # a group's member belongs to the group
+                lib().ndt_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -283,12 +364,7 @@ class NDT:
         res = np.zeros(n_pairs, RESULT_DTYPE)
         self._chk(lib().ndt_align_batch_resident(self._h, None if ps is None else ps.ctypes.data, n_pairs, g.ctypes.data,
                                                  C.cast(res.ctypes.data, C.POINTER(Result))))
-        T = res["T"].reshape(n_pairs, 4, 4).transpose(0, 2, 1)
-        H = res["H"].reshape(n_pairs, 6, 6)
-        return [dict(rc=int(st), status=int(st), T=T[i], H=H[i], b=res["b"][i], chi2=float(res["chi2"][i]),
-                     n_effective=int(res["n_effective"][i]), iterations=int(res["iterations"][i]),
-                     converged=bool(res["converged"][i]), last_dx_norm=float(res["last_dx_norm"][i]))
-                for i, st in enumerate(res["status"])]
+        return _unpack_results(res)
 
     def getFinalTransformation(self): return self.final["T"]
     def hasConverged(self): return self.final["converged"]
