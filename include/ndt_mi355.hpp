@@ -127,6 +127,25 @@ class NormalDistributionsTransform {
         return blob;
     }
     void loadMap(const std::vector<unsigned char>& blob) { check(ndt_map_load(handle(), blob.data(), blob.size())); }
+    // Offline replay (ndt_align_batch; no counterpart in the reference, which aligns one frame at a time): many
+    // (scan, initial pose) pairs against the resident target in one batched Gauss-Newton loop.  pair_scan[p] is the
+    // scan of pair p (empty: pair p uses scan p); guesses are column-major 4x4.  results[p].status tells how pair p ended.
+    template <class Cloud>
+    std::vector<ndt_result> alignBatch(const std::vector<Cloud>& scans, const std::vector<int32_t>& pair_scan,
+                                       const std::vector<Matrix4d>& guesses) {
+        std::vector<PointSource> pts;
+        std::vector<int64_t> off(scans.size() + 1, 0);
+        for (size_t i = 0; i < scans.size(); ++i) {
+            off[i + 1] = off[i] + (int64_t)scans[i].size();
+            pts.insert(pts.end(), scans[i].data(), scans[i].data() + scans[i].size());
+        }
+        std::vector<double> g(16 * guesses.size());
+        for (size_t p = 0; p < guesses.size(); ++p) for (int i = 0; i < 16; ++i) g[16 * p + i] = guesses[p][i];
+        std::vector<ndt_result> out(guesses.size());
+        check(ndt_align_batch(handle(), pts.data(), sizeof(PointSource), off.data(), scans.size(), pair_scan.empty() ? nullptr : pair_scan.data(),
+                              guesses.size(), g.data(), out.data()));
+        return out;
+    }
     const ndt_result& result() const { return res_; }
     int status() const { return status_; }
     std::string lastError() const { return h_ ? ndt_last_error(h_) : "no handle"; }

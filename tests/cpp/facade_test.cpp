@@ -1,6 +1,9 @@
 // Drives the C++ facade the way src/slam/src/process.cc drives its PCL member (lines 373-376, 78, 87, 94-95, 147),
 // on clouds of the reference's own 32-byte point record.  Input: a binary file written by tests/test_gpu_facade.py;
 // output: pose, Hessian, iteration count as text.
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +59,18 @@ int main(int argc, char** argv) {
     printf("\n");
     for (double v : H) printf("%.17g ", v);
     printf("\n");
+    // offline replay through the facade: the same pair twice and once from the result pose
+    {
+        std::array<double, 16> g0, g1 = T;
+        for (int i = 0; i < 16; ++i) g0[i] = guess[i];
+        std::vector<PointCloud> scans{*scan};
+        auto rb = ndt_.alignBatch(scans, {0, 0, 0}, {g0, g1, g0});
+        double d = 0.0;
+        for (int i = 0; i < 16; ++i) d = std::max(d, std::fabs(rb[0].T[i] - T[i]));
+        bool same = true;
+        for (int i = 0; i < 16; ++i) same = same && rb[0].T[i] == rb[2].T[i];
+        printf("batch %d %d %d %.3g %d\n", rb[0].status, rb[1].status, rb[0].iterations, d, (int)same);
+    }
     // the same call sequence in PCL compatibility mode (what the reference's PCL build computes at process.cc:94)
     ndt_.setPclCompatibility(true);
     ndt_.align(output, guess);

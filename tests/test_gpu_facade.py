@@ -38,9 +38,12 @@ def test_cpp_facade_matches_oracle(tmp_path):
     dt, dr = pose_error(T, r["T"])
     assert dt < 1e-4 and dr < 1e-5
     assert rel_err(H, r["H"]) < 1e-5
+    # alignBatch: pair 0 = the same problem (same pose up to the batch's summation order), pair 2 = pair 0 bit for bit
+    bt = lines[3].split()
+    assert bt[0] == "batch" and int(bt[1]) == 0 and int(bt[2]) == 0 and int(bt[3]) == r["iterations"] and float(bt[4]) < 1e-9 and int(bt[5]) == 1
     # PCL compatibility mode through the same facade calls
-    st2 = lines[3].split()
-    Tp = np.array(lines[4].split(), float).reshape(4, 4).T
+    st2 = lines[4].split()
+    Tp = np.array(lines[5].split(), float).reshape(4, 4).T
     o.set_params(max_iterations=35, eps=0.01)
     rp = o.pcl_align(guess32.astype(np.float64), step_size=0.1)
     assert int(st2[1]) == 0 and int(st2[3]) == int(rp["converged"]) and int(st2[5]) == rp["iterations"]
