@@ -296,6 +296,10 @@ int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_pe
 int ndt_time_residual_batch(ndt_handle* h, int reps, double* us_per_launch, double* points_per_launch,
                             double* hits_per_point);
 
+/* Radix-sort passes (8-bit digits) the last map build / merge executed: the P of SURVEY.md §8(d)'s
+ * B_build = 12 + 12 + 24 P + 12 bytes per target point (measurement only). */
+int ndt_last_radix_passes(const ndt_handle* h);
+
 /* Blocks until all work queued on the handle's stream has finished. */
 int ndt_synchronize(ndt_handle* h);
 

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
-    "ndt_last_error", "ndt_version",
+    "ndt_last_error", "ndt_version", "ndt_last_radix_passes",
     "ndt_create_group", "ndt_destroy_group", "ndt_group_size", "ndt_group_handle", "ndt_group_set_target", "ndt_group_add_target",
     "ndt_group_align_batch", "ndt_group_last_error",
 ]
@@ -119,6 +119,7 @@ def lib():
     L.ndt_align_batch.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     L.ndt_set_batch_sources.argtypes = [vp, vp, sz, vp, sz]
     L.ndt_align_batch_resident.argtypes = [vp, vp, sz, vp, vp]
+    L.ndt_last_radix_passes.argtypes = [vp]
     L.ndt_create_group.restype = vp
     L.ndt_create_group.argtypes = [vp, C.c_int, vp]
     L.ndt_destroy_group.argtypes = [vp]
@@ -317,6 +318,7 @@ class NDT:
 
     setInputTarget, setInputSource = set_target, set_source
 
+    def last_radix_passes(self): return lib().ndt_last_radix_passes(self._h)
     def source_size(self): return lib().ndt_source_size(self._h)
     def num_voxels(self): return lib().ndt_num_voxels(self._h)
 

@@ -286,6 +286,7 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]) {
     return rc;
 }
 
+int ndt_last_radix_passes(const ndt_handle* h) { return h ? h->last_radix_passes : 0; }
 int64_t ndt_source_size(const ndt_handle* h) { return h ? (int64_t)h->n_src : 0; }
 int64_t ndt_num_voxels(const ndt_handle* h) { return h ? h->map.n_vox : 0; }
 
