@@ -784,9 +784,18 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
     if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
     const unsigned char* d_in = (const unsigned char*)pts;
     if (stride) {
-        HIP_TRY(w.raw.ensure(n * stride));
-        HIP_TRY(hipMemcpyAsync(w.raw.p, pts, n * stride, hipMemcpyDefault, s));
-        d_in = (const unsigned char*)w.raw.p;
+        // records already in device memory are read in place (k_target_keys is their only reader and runs before this
+        // function's first synchronisation, so the caller's buffer is free again on return either way)
+        hipPointerAttribute_t at;
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        const bool on_device = hipPointerGetAttributes(&at, pts) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == dev;
+        if (!on_device) {
+            (void)hipGetLastError();                 // a plain host pointer makes the query fail: not an error
+            HIP_TRY(w.raw.ensure(n * stride));
+            HIP_TRY(hipMemcpyAsync(w.raw.p, pts, n * stride, hipMemcpyDefault, s));
+            d_in = (const unsigned char*)w.raw.p;
+        }
     }
     HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
     HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.keys_b.ensure(n * 8));
