@@ -415,9 +415,12 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     const int max_it = h->cfg.max_iterations;
     // With eps == 0 the loop cannot stop early: queue everything and look once.
     const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
-    // (profiling times the residual launches alone; every block re-reads all rows of the previous launch, which only pays
-    // while there are few: a 2 M-point source has 2048 rows = 512 KB per block)
-    const bool chained = h->use_chain && !h->comm && !h->prof && h->n_src > 0 && residual_grid(h->n_src) <= 512;
+    // (profiling times the residual launches alone; every block re-reads all rows of the previous launch and repeats the
+    // solve, which only pays while no CU runs more than one block per launch: measured, 230 blocks 0.134 -> 0.123 ms per
+    // align, 489 blocks 0.191 -> 0.221 ms)
+    const bool chain_fits = h->use_chain && !h->prof && h->n_src > 0 && residual_grid(h->n_src) <= residual_cu_count();
+    const bool chained = chain_fits && !h->comm;
+    const bool chained_comm = chain_fits && h->comm;
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     int queued = 0;
@@ -434,6 +437,22 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
                 std::swap(h->partials, h->partials2);             // partials2 = the rows just written
             }
             launch_reduce_solve(h->partials2.as<double>(), grid, h->d_state, sp, 1, 0, h->stream);
+            H_TRY(hipGetLastError());
+        } else if (chained_comm) {
+            // sharded source: launch i takes the step from the all-reduced row of launch i - 1 in its prologue (one "row" to sum),
+            // then residual -> local fixed-order sum -> all-reduce; three launches per iteration instead of four
+            const int grid = residual_grid(h->n_src);
+            double* send = h->comm_rows.as<double>();
+            double* recv = send + ACC_N;
+            for (int i = 0; i < m; ++i) {
+                launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
+                                      (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, recv, i ? 1 : 0, sp, ep, h->partials.as<double>(), grid,
+                                      h->use_links, h->stream);
+                std::swap(h->d_state, h->d_state2);
+                launch_reduce_rows(h->partials.as<double>(), grid, h->d_state, send, 0, h->stream);
+                if (g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream) != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
+            }
+            launch_solve_only(h->d_state, recv, sp, 1, 0, h->stream);
             H_TRY(hipGetLastError());
         } else {
             for (int i = 0; i < m; ++i)

@@ -109,6 +109,7 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 
 // ---- ndt_residual.hip
 int residual_grid(size_t n, size_t problems = 1);
+int residual_cu_count();
 void residual_set_cu_count(int n);        // compute units of the device (256 on MI355X): sizes the batched grids
 // chained single-scan iteration: previous launch's reduction + step in every block's prologue, then the residual pass
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 // there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
 static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on several host threads
 void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
+int residual_cu_count() { return g_cu_count.load(std::memory_order_relaxed); }
 int residual_grid(size_t n, size_t problems) {
     if (problems <= 1) {                              // k_residual: 512-thread blocks, one point per lane up to 2048 blocks
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;

@@ -137,15 +137,15 @@ def test_two_handles_on_two_host_threads_are_independent():
 def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
     """The single-scan loop runs one launch per iteration (the previous iteration's reduction + step in every block's
     prologue); NDT_NO_CHAIN=1 runs residual and reduce/solve as two launches.  Same sums in the same order, same step:
-    identical bits, for a loop that stops early (eps), one that runs to the cap, one that fails, a source of ~400 rows
-    (more than one 256-row trip of the prologue's sum) and one above the 512-row limit of the chained form."""
+    identical bits, for a loop that stops early (eps), one that runs to the cap, one that fails, a source that
+    fills the chained form's limit (one block per CU: 250 rows) and one above it (which runs as two launches either way)."""
     import lio_slam_amd as la
     from lio_slam_amd import synth
     c = synth.make_config(1, small=True)
     rng = np.random.default_rng(3)
     far = c["guess"].copy(); far[:3, 3] += [300.0, 0, 0]                      # no voxel in reach: too few residuals
     big = np.concatenate([c["scan"] + rng.normal(0, 0.01, c["scan"].shape).astype(np.float32) for _ in range(40)])
-    mid = big[: 400 * 512 - 77]
+    mid = big[: 250 * 512 - 77]
     res = []
     for no_chain in (False, True):
         if no_chain:
@@ -165,7 +165,7 @@ def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
                 out.append(n.align(c["guess"]))
             n.close()
         res.append(out)
-    assert 256 * 512 < len(mid) <= 512 * 512 < len(big)
+    assert 249 * 512 < len(mid) <= 256 * 512 < len(big)
     for a, b in zip(*res):
         assert a["iterations"] == b["iterations"] and a["converged"] == b["converged"]
         for k in ("T", "H", "b"):
