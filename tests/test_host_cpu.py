@@ -124,3 +124,22 @@ def test_information_from_hessian():
         la.information_from_hessian(np.zeros((6, 6)))
     with pytest.raises(la.NdtError):
         la.information_from_hessian(np.full((6, 6), np.nan))
+
+
+def test_public_headers_compile_standalone(tmp_path):
+    """include/ndt_mi355.h is a C header (gcc -std=c99), the three .hpp files are C++17, each self-contained, warning-free
+    under -Wall -Wextra, and need nothing beyond the standard library (no Eigen / PCL / ROS / HIP headers)."""
+    import shutil
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    if not shutil.which("gcc") or not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    c = tmp_path / "abi.c"
+    c.write_text('#include "ndt_mi355.h"\nint main(void) { ndt_config c; ndt_result r; (void)c; (void)r; return NDT_OK; }\n')
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(c)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for hdr in ("ndt_mi355.hpp", "ndt_mi355_odometry.hpp", "ndt_mi355_lio.hpp"):
+        cc = tmp_path / (hdr + ".cpp")
+        cc.write_text(f'#include "{hdr}"\nint main() {{ return 0; }}\n')
+        out = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cc)], capture_output=True, text=True)
+        assert out.returncode == 0, hdr + "\n" + out.stderr
