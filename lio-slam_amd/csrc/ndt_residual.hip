@@ -373,8 +373,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 }
 
 // Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
-// the whole launch is small (latency-bound: every wave should be resident at once); up to 8 points per lane once
-// there are several waves per SIMD anyway, which amortises the per-wave reduction tail and shrinks the row count.
+// the whole launch is small (latency-bound: every wave should be resident at once); more points per lane once the
+// launch would not fit the GPU in one go, which amortises the per-block reduction tail and shrinks the row count.
 static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on several host threads
 void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
 int residual_cu_count() { return g_cu_count.load(std::memory_order_relaxed); }
@@ -385,11 +385,12 @@ int residual_grid(size_t n, size_t problems) {
     }
     // Batched launches: 256-thread blocks, two resident per CU (241 VGPRs), each lane works through `ppt` points.  The
     // grid is chosen against the tail effect: time ~ (rounds of resident blocks) x (points per lane + 2 for the block's
-    // reduction and row store), ties to the longer lane loop: 8 pairs of 118 k points run as 464 blocks of 8 points per
-    // lane (one round) rather than 528 blocks of 7 (two rounds); large batches settle on 8 (measured: DESIGN.md §5).
+    // reduction and row store).  In effect: the fewest points per lane for which the whole launch is ONE round of resident
+    // blocks — 8 pairs of 118 k points run as 464 blocks of 8 points per lane rather than 528 blocks of 7 (two rounds),
+    // 32 pairs as 512 blocks of 29, 128 pairs as 512 blocks of 115 (measured sweeps: DESIGN.md §5).
     const size_t resident = (size_t)2 * (size_t)g_cu_count.load(std::memory_order_relaxed);
     size_t best_ppt = 1, best_cost = ~(size_t)0;
-    for (size_t ppt = 8; ppt >= 1; --ppt) {
+    for (size_t ppt = 128; ppt >= 1; --ppt) {
         const size_t rows = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
         const size_t rounds = (rows * problems + resident - 1) / resident;
         const size_t cost = rounds * (ppt + 2);
