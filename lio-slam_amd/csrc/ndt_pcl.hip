@@ -476,8 +476,10 @@ struct Driver {
 }  // namespace
 
 int pcl_grid(size_t n) {
+    // one point per lane up to one round of resident blocks (two 256-thread blocks per CU at 256 VGPRs), then the lanes loop
     size_t g = (n + PCL_THREADS - 1) / PCL_THREADS;
-    return (int)(g < 1 ? 1 : g > 4096 ? 4096 : g);
+    const size_t cap = (size_t)2 * (size_t)residual_cu_count();
+    return (int)(g < 1 ? 1 : g > cap ? cap : g);
 }
 
 void pcl_matrix_from_vector(const double p[6], double T[16]) {

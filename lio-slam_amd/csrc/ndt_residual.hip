@@ -379,9 +379,13 @@ static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on
 void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
 int residual_cu_count() { return g_cu_count.load(std::memory_order_relaxed); }
 int residual_grid(size_t n, size_t problems) {
-    if (problems <= 1) {                              // k_residual: 512-thread blocks, one point per lane up to 2048 blocks
+    if (problems <= 1) {                              // k_residual: 512-thread blocks
+        // one point per lane while that fits one round of resident blocks (one 512-thread block per CU at 256 VGPRs); beyond
+        // that the lanes loop, the launch stays one round and its rows stay few enough for the chained loop (2 M points:
+        // 0.72 -> 0.53 ms per 10-iteration align against a 2048-block grid)
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
-        return (int)(g < 1 ? 1 : g > 2048 ? 2048 : g);
+        const size_t cap = (size_t)g_cu_count.load(std::memory_order_relaxed);
+        return (int)(g < 1 ? 1 : g > cap ? cap : g);
     }
     // Batched launches: 256-thread blocks, two resident per CU (241 VGPRs), each lane works through `ppt` points.  The
     // grid is chosen against the tail effect: time ~ (rounds of resident blocks) x (points per lane + 2 for the block's
