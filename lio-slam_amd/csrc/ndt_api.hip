@@ -760,7 +760,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
         lanes[l].p0 = l * per; lanes[l].np = std::min(per, n_pairs - l * per);
     }
     const size_t group = std::min(CH, lanes[0].np);      // the largest launch: sizes the grid rows for all of them
-    const int rows = residual_grid((size_t)max_pts, group);
+    const int rows = residual_grid((size_t)max_pts, group, h->cfg.nearby);
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));

@@ -108,7 +108,7 @@ int pcl_align(const PclEngine& e, const ndt_pcl_params& prm, int max_iterations,
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
 
 // ---- ndt_residual.hip
-int residual_grid(size_t n, size_t problems = 1);
+int residual_grid(size_t n, size_t problems = 1, int nearby = 7);
 int residual_cu_count();
 void residual_set_cu_count(int n);        // compute units of the device (256 on MI355X): sizes the batched grids
 // chained single-scan iteration: previous launch's reduction + step in every block's prologue, then the residual pass

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on several host threads
 void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
 int residual_cu_count() { return g_cu_count.load(std::memory_order_relaxed); }
-int residual_grid(size_t n, size_t problems) {
+int residual_grid(size_t n, size_t problems, int nearby) {
     if (problems <= 1) {                              // k_residual: 512-thread blocks
         // one point per lane while that fits one round of resident blocks (one 512-thread block per CU at 256 VGPRs); beyond
         // that the lanes loop, the launch stays one round and its rows stay few enough for the chained loop (2 M points:
@@ -392,7 +392,8 @@ int residual_grid(size_t n, size_t problems) {
     // reduction and row store).  In effect: the fewest points per lane for which the whole launch is ONE round of resident
     // blocks — 8 pairs of 118 k points run as 464 blocks of 8 points per lane rather than 528 blocks of 7 (two rounds),
     // 32 pairs as 512 blocks of 29, 128 pairs as 512 blocks of 115 (measured sweeps: DESIGN.md §5).
-    const size_t resident = (size_t)2 * (size_t)g_cu_count.load(std::memory_order_relaxed);
+    // (NEARBY1 needs 138 VGPRs and is bandwidth-bound: measured best with four blocks per CU in flight)
+    const size_t resident = (size_t)(nearby == 1 ? 4 : 2) * (size_t)g_cu_count.load(std::memory_order_relaxed);
     size_t best_ppt = 1, best_cost = ~(size_t)0;
     for (size_t ppt = 128; ppt >= 1; --ppt) {
         const size_t rows = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);
