@@ -174,28 +174,26 @@ __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float y
 // face neighbours (ghost cells make sure a cell next to a voxel is always in the table).  Same probe order and the
 // same arithmetic as point_terms<7>, so both give identical bits.
 // first half: transform, cell, hash, and the two 16-byte key reads of the point's own cell (issued, not yet used)
-struct CentreProbe { uint32_t s0; Key2 ka, kb; };
+struct CentreProbe { uint32_t s0; Key2 ka, kb; double q[3]; int32_t c[3]; bool ok; };
 __device__ __forceinline__ CentreProbe centre_probe(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys, uint32_t mask,
                                                     const EvalParams& ep) {
-    double q[3];
-    ndt_xform(P.R, P.t, xf, yf, zf, q);
-    int32_t c[3];
-    const bool ok = ndt_source_cell(ep.kp, q, c);
     CentreProbe pr;
-    pr.s0 = ok ? ndt_hash_cell(c[0], c[1], c[2]) & mask : 0u;
+    ndt_xform(P.R, P.t, xf, yf, zf, pr.q);
+    pr.ok = ndt_source_cell(ep.kp, pr.q, pr.c);
+    pr.s0 = pr.ok ? ndt_hash_cell(pr.c[0], pr.c[1], pr.c[2]) & mask : 0u;
     const Key2* kp = (const Key2*)(keys + pr.s0);
     pr.ka = kp[0]; pr.kb = kp[1];
     return pr;
 }
 // second half: resolve the centre entry from the keys already read, then links, payloads, gate and fold.  The
-// transformed point and its cell are recomputed (27 flops) rather than carried across the software-pipeline stage.
+// transformed point and its cell travel with the probe (10 registers across the software-pipeline stage; recomputing
+// them cost 40 instructions per point).
 __device__ __forceinline__ unsigned point_terms_from_probe(const Pose& P, float xf, float yf, float zf, const CentreProbe& pr,
                                                            const int64_t* __restrict__ keys, const VoxSlot* __restrict__ slots, uint32_t mask,
                                                            const EvalParams& ep, double* acc, int64_t* cell_key) {
-    double q[3];
-    ndt_xform(P.R, P.t, xf, yf, zf, q);
-    int32_t c[3];
-    if (!ndt_source_cell(ep.kp, q, c)) { *cell_key = NDT_KEY_EMPTY; return 0; }
+    if (!pr.ok) { *cell_key = NDT_KEY_EMPTY; return 0; }
+    const double* q = pr.q;
+    const int32_t* c = pr.c;
     const int64_t ckey = ndt_pack(c[0], c[1], c[2]);
     *cell_key = ckey;
     const uint32_t s0 = pr.s0;
