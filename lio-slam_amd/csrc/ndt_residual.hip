@@ -59,44 +59,42 @@ __device__ __forceinline__ unsigned gate_and_sum(const Payload* pay, const uint3
     return hitmask;
 }
 
-// Folds one point's S and g through J = [-R hat(q) | I] into the 21 + 6 accumulators.
-__device__ __forceinline__ void fold_point(const Pose& P, float xf, float yf, float zf, unsigned hitmask, const double* S, const double* g,
-                                           double* acc) {
+// Folds one point's S = sum Sigma^-1 and g = sum Sigma^-1 e into the 21 + 6 accumulators, in the WORLD frame.
+// With u = R x (the point's lever arm, q - t) and K = hat(u):  J = [-R hat(x) | I] = [-K R | I], so
+//   H = [R^T M R, R^T N; N^T R, S]  with  M = K^T S K = -(K S) K,  N = K S,      b = [-R^T (u x g); -g].
+// The lanes accumulate the pose-independent sums M (6), N (9), S (6), u x g (3), -g (3) in the slots of the H / b entries
+// they turn into; raw_to_Hb applies R once per reduced row (in the reduce / solve kernels).  57 float64 instructions per
+// point instead of the 90 that forming A = -R hat(x), S A and A^T S A took.
+// (explicit fma: this part is compared at the 1e-5 tolerance, not bit for bit)
+__device__ __forceinline__ void fold_point(const Pose& P, const double* q, unsigned hitmask, const double* S, const double* g, double* acc) {
     if (!__any(hitmask != 0)) return;
-    // A = -R hat(q):  H = [A^T S A, A^T S; S A, S],  b = [-A^T g; -g]
-    const double x = xf, y = yf, z = zf;
-    const double* R = P.R;
-    // (explicit fma from here on: this part is compared at the 1e-5 tolerance, not bit for bit)
-    double A[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        A[r][0] = fma(R[3 * r + 2], y, -(R[3 * r + 1] * z));
-        A[r][1] = fma(R[3 * r + 0], z, -(R[3 * r + 2] * x));
-        A[r][2] = fma(R[3 * r + 1], x, -(R[3 * r + 0] * y));
-    }
+    const double u0 = q[0] - P.t[0], u1 = q[1] - P.t[1], u2 = q[2] - P.t[2];
     const double Sm[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
-    double SA[3][3];
+    double n[3][3];                                   // n = K S
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) SA[r][cc] = fma(Sm[r][2], A[2][cc], fma(Sm[r][1], A[1][cc], Sm[r][0] * A[0][cc]));
-    // upper triangle of the 6x6, row-major: rows 0..2 = [A^T S A](r, r..2) then [A^T S](r, 0..2); rows 3..5 = S
-    int tix = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int cc = r; cc < 3; ++cc) { acc[tix] = fma(A[0][r], SA[0][cc], fma(A[1][r], SA[1][cc], fma(A[2][r], SA[2][cc], acc[tix]))); ++tix; }
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) acc[tix++] += SA[cc][r];
+    for (int c = 0; c < 3; ++c) {
+        n[0][c] = fma(u1, Sm[2][c], -(u2 * Sm[1][c]));
+        n[1][c] = fma(u2, Sm[0][c], -(u0 * Sm[2][c]));
+        n[2][c] = fma(u0, Sm[1][c], -(u1 * Sm[0][c]));
     }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = r; cc < 3; ++cc) acc[tix++] += Sm[r][cc];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[21 + r] = fma(-A[0][r], g[0], fma(-A[1][r], g[1], fma(-A[2][r], g[2], acc[21 + r])));
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[24 + r] -= g[r];
+    // M = -(n K), upper triangle;  (n K)_i0 = n_i1 u2 - n_i2 u1,  (n K)_i1 = n_i2 u0 - n_i0 u2,  (n K)_i2 = n_i0 u1 - n_i1 u0
+    acc[0] = fma(n[0][2], u1, fma(-n[0][1], u2, acc[0]));
+    acc[1] = fma(n[0][0], u2, fma(-n[0][2], u0, acc[1]));
+    acc[2] = fma(n[0][1], u0, fma(-n[0][0], u1, acc[2]));
+    acc[6] = fma(n[1][0], u2, fma(-n[1][2], u0, acc[6]));
+    acc[7] = fma(n[1][1], u0, fma(-n[1][0], u1, acc[7]));
+    acc[11] = fma(n[2][1], u0, fma(-n[2][0], u1, acc[11]));
+    // N
+    acc[3] += n[0][0]; acc[4] += n[0][1]; acc[5] += n[0][2];
+    acc[8] += n[1][0]; acc[9] += n[1][1]; acc[10] += n[1][2];
+    acc[12] += n[2][0]; acc[13] += n[2][1]; acc[14] += n[2][2];
+    // S
+    acc[15] += Sm[0][0]; acc[16] += Sm[0][1]; acc[17] += Sm[0][2]; acc[18] += Sm[1][1]; acc[19] += Sm[1][2]; acc[20] += Sm[2][2];
+    // u x g and -g
+    acc[21] = fma(u1, g[2], fma(-u2, g[1], acc[21]));
+    acc[22] = fma(u2, g[0], fma(-u0, g[2], acc[22]));
+    acc[23] = fma(u0, g[1], fma(-u1, g[0], acc[23]));
+    acc[24] -= g[0]; acc[25] -= g[1]; acc[26] -= g[2];
 }
 
 // Accumulates one source point into acc[0..29].  Returns the hit mask; *cell_key gets the centre key (or EMPTY).
@@ -166,7 +164,7 @@ __device__ __forceinline__ unsigned point_terms(const Pose& P, float xf, float y
     for (int pr = 0; pr < K; ++pr) pay[pr] = load_payload(slots, fs[pr]);
     double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     const unsigned hitmask = gate_and_sum<K>(pay, fs, q, c, ep, S, g, acc);
-    fold_point(P, xf, yf, zf, hitmask, S, g, acc);
+    fold_point(P, q, hitmask, S, g, acc);
     return hitmask;
 }
 
@@ -229,7 +227,7 @@ __device__ __forceinline__ unsigned point_terms_from_probe(const Pose& P, float 
     for (int prb = 1; prb < 7; ++prb) pay[prb] = load_payload(slots, fs[prb]);
     double S[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     const unsigned hitmask = gate_and_sum<7>(pay, fs, q, c, ep, S, g, acc);
-    fold_point(P, xf, yf, zf, hitmask, S, g, acc);
+    fold_point(P, q, hitmask, S, g, acc);
     return hitmask;
 }
 __device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, float yf, float zf, const int64_t* __restrict__ keys,
@@ -275,6 +273,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
 // iteration instead of two: the 4 us one-block kernel, its launch gap and its end-of-kernel write-back leave the
 // critical path; the price is ~60 KB of L2 reads and one serial solve per block.  n_prev = 0: no pending step.
 __device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp);
+__device__ __forceinline__ double hb_entry(const double* R, const double* raw, int e);
 __device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
 
 template <int K, bool LINKED>
@@ -293,10 +292,14 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     if (threadIdx.x < ST_WORDS) ((double*)&sst)[threadIdx.x] = ((const double*)st_in)[threadIdx.x];
     if (n_prev > 0) reduce_rows32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
     else __syncthreads();
+    if (n_prev > 0) {          // (uniform) world-frame sums -> H, b: one lane per entry; sst still holds the pose the rows were computed at
+        if (threadIdx.x < ACC_N && !sst.done) sm[1][threadIdx.x] = hb_entry(sst.R, sm[0], threadIdx.x);
+        __syncthreads();
+    }
     if (n_prev > 0 && threadIdx.x == 0 && !sst.done) {
         double acc0[ACC_N];
 #pragma unroll
-        for (int j = 0; j < ACC_N; ++j) { acc0[j] = sm[0][j]; sst.acc[j] = acc0[j]; }
+        for (int j = 0; j < ACC_N; ++j) { acc0[j] = sm[1][j]; sst.acc[j] = acc0[j]; }
         gn_step(&sst, acc0, sp);
     }
     __syncthreads();
@@ -455,6 +458,37 @@ __device__ inline bool ldlt_solve6(const double* H, const double* b, double* x) 
     return true;
 }
 
+// Reduced world-frame sums (fold_point) -> H and b at the pose with rotation R (row-major):
+// H_rr = R^T M R, H_rt = R^T N, b_rot = -R^T (sum u x g); S, -sum g, chi2 and the counters are already final.
+// hb_entry gives entry e of the converted row in one fixed operation order, so a block can convert with one lane per
+// entry (the latency-critical single-scan kernels) or one lane for all of them (raw_to_Hb) and get the same bits.
+// decode tables as immediates (a table in memory would put a dependent load chain into the single-scan prologue):
+// entry e -> kind (1: H_rr(i,j), 2: H_rt(i,j), 3: b_rot(i), 0: as is), i, j, two bits each; slot of M(k,l), four bits each
+#define HB_KIND_BITS 0x0000fc002a6a5a95ull
+#define HB_I_BITS 0x000090002a955000ull
+#define HB_J_BITS 0x0000000024a49924ull
+#define HB_M_BITS 0x0000000b72761210ull
+__device__ __forceinline__ int hb_m_slot(int k, int l) { return (int)((HB_M_BITS >> (4 * (3 * k + l))) & 15ull); }
+__device__ __forceinline__ int hb_n_slot(int k, int j) { return (k == 0 ? 3 : k == 1 ? 8 : 12) + j; }
+__device__ __forceinline__ double hb_entry(const double* R, const double* raw, int e) {
+    const int kind = (int)((HB_KIND_BITS >> (2 * e)) & 3ull), i = (int)((HB_I_BITS >> (2 * e)) & 3ull), j = (int)((HB_J_BITS >> (2 * e)) & 3ull);
+    if (kind == 0) return raw[e];
+    double t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (kind == 1) t[k] = (raw[hb_m_slot(k, 0)] * R[j] + raw[hb_m_slot(k, 1)] * R[3 + j]) + raw[hb_m_slot(k, 2)] * R[6 + j];   // (M R)(k,j)
+        else if (kind == 2) t[k] = raw[hb_n_slot(k, j)];
+        else t[k] = raw[21 + k];
+    }
+    const double v = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
+    return kind == 3 ? -v : v;
+}
+__device__ void raw_to_Hb(const double* R, double* acc) {
+    double out[ACC_N];
+    for (int e = 0; e < ACC_N; ++e) out[e] = hb_entry(R, acc, e);
+    for (int e = 0; e < ACC_N; ++e) acc[e] = out[e];
+}
+
 // One Gauss-Newton step from the reduced accumulators: dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6]
 // (Exp: Rodrigues as src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad).
 __device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp) {
@@ -571,11 +605,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
     const int done = st->done;
     reduce_rows<32>(partials, n_partials, sm, true);
     if (!force && done) return;
-    if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
+    if (threadIdx.x < ACC_N) {          // world-frame sums -> H, b at the state's pose, one lane per entry
+        const double v = hb_entry(st->R, sm[0], threadIdx.x);
+        sm[1][threadIdx.x] = v;
+        st->acc[threadIdx.x] = v;
+    }
+    __syncthreads();
     if (do_solve && threadIdx.x == 0) {
         double acc[ACC_N];
 #pragma unroll
-        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[0][j];
+        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[1][j];
         gn_step(st, acc, sp);
     }
 }
@@ -588,12 +627,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __res
 }
 __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp, int do_solve, int force) {
     if (!force && st->done) return;
-    if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = reduced[threadIdx.x];
-    if (do_solve && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         double acc[ACC_N];
 #pragma unroll
         for (int j = 0; j < ACC_N; ++j) acc[j] = reduced[j];
-        gn_step(st, acc, sp);
+        raw_to_Hb(st->R, acc);
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) st->acc[j] = acc[j];
+        if (do_solve) gn_step(st, acc, sp);
     }
 }
 
@@ -603,13 +644,17 @@ __device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnS
     __shared__ double sm[BRED_THREADS / 32][ACC_N + 1];
     reduce_rows<BRED_THREADS / 32>(partials, rows_per_pair, sm, true);
     if (!force && st->done) return;
-    if (threadIdx.x < ACC_N) st->acc[threadIdx.x] = sm[0][threadIdx.x];
-    if (do_solve && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         double acc[ACC_N];
 #pragma unroll
         for (int j = 0; j < ACC_N; ++j) acc[j] = sm[0][j];
-        gn_step(st, acc, sp);
-        if (st->done) atomicAdd(n_done, 1);
+        raw_to_Hb(st->R, acc);
+#pragma unroll
+        for (int j = 0; j < ACC_N; ++j) st->acc[j] = acc[j];
+        if (do_solve) {
+            gn_step(st, acc, sp);
+            if (st->done) atomicAdd(n_done, 1);
+        }
     }
 }
 __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
