@@ -118,12 +118,21 @@ __device__ inline bool ndt_target_cell(const KeyParams& kp, float x, float y, fl
 }
 // cell of a float64 transformed source point: same rule evaluated in float64
 __device__ inline bool ndt_source_cell(const KeyParams& kp, const double q[3], int32_t c[3]) {
+    double v[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        double v = q[j] * kp.inv_res_d;
-        v = kp.key_rule == 0 ? floor(v) : round(v);
-        if (!ndt_in_range(v)) return false;
-        c[j] = (int32_t)v;
+    for (int j = 0; j < 3; ++j) v[j] = q[j] * kp.inv_res_d;
+    // the rule is uniform over the launch: a real branch, not both roundings and a select (the empty asm keeps the
+    // compiler from speculating the rarely used half-away rounding into the hot loop)
+    if (kp.key_rule == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = floor(v[j]);
+    } else {
+        asm volatile("");
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = round(v[j]);
     }
-    return true;
+    const bool ok = ndt_in_range(v[0]) && ndt_in_range(v[1]) && ndt_in_range(v[2]);      // false for NaN / inf too
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] = ok ? (int32_t)v[j] : 0;
+    return ok;
 }
