@@ -643,18 +643,19 @@ __global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp,
 __device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done) {
     __shared__ double sm[BRED_THREADS / 32][ACC_N + 1];
     reduce_rows<BRED_THREADS / 32>(partials, rows_per_pair, sm, true);
-    if (!force && st->done) return;
-    if (threadIdx.x == 0) {
+    if (!force && st->done) return;            // (uniform over the block: nobody has written the state yet)
+    if (threadIdx.x < ACC_N) {                 // world-frame sums -> H, b at the state's pose, one lane per entry
+        const double v = hb_entry(st->R, sm[0], threadIdx.x);
+        sm[1][threadIdx.x] = v;
+        st->acc[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (do_solve && threadIdx.x == 0) {
         double acc[ACC_N];
 #pragma unroll
-        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[0][j];
-        raw_to_Hb(st->R, acc);
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) st->acc[j] = acc[j];
-        if (do_solve) {
-            gn_step(st, acc, sp);
-            if (st->done) atomicAdd(n_done, 1);
-        }
+        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[1][j];
+        gn_step(st, acc, sp);
+        if (st->done) atomicAdd(n_done, 1);
     }
 }
 __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
