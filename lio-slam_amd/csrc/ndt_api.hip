@@ -411,7 +411,6 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     H_TRY(hipSetDevice(h->cfg.device));
     memset(out, 0, sizeof *out);
     state_from_T(h->h_state, guess);
-    H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
     const int max_it = h->cfg.max_iterations;
     // With eps == 0 the loop cannot stop early: queue everything and look once.
     const int chunk = h->cfg.eps > 0.0 ? SYNC_CHUNK : max_it;
@@ -421,6 +420,10 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     const bool chain_fits = h->use_chain && !h->prof && h->n_src > 0 && residual_grid(h->n_src) <= residual_cu_count();
     const bool chained = chain_fits && !h->comm;
     const bool chained_comm = chain_fits && h->comm;
+    // the chained loop's first launch takes the initial pose as a kernel argument; the other forms read it from HBM
+    if (!chained) H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    GnState init_state = *h->h_state;
+    bool first_launch = true;
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     int queued = 0;
@@ -432,7 +435,8 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
             for (int i = 0; i < m; ++i) {
                 launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
                                       (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, h->partials2.as<double>(), i ? grid : 0, sp, ep,
-                                      h->partials.as<double>(), grid, h->use_links, h->stream);
+                                      h->partials.as<double>(), grid, h->use_links, first_launch ? &init_state : nullptr, h->stream);
+                first_launch = false;
                 std::swap(h->d_state, h->d_state2);               // the launch published the state it used in st_out
                 std::swap(h->partials, h->partials2);             // partials2 = the rows just written
             }
@@ -447,7 +451,7 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
             for (int i = 0; i < m; ++i) {
                 launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
                                       (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, recv, i ? 1 : 0, sp, ep, h->partials.as<double>(), grid,
-                                      h->use_links, h->stream);
+                                      h->use_links, nullptr, h->stream);
                 std::swap(h->d_state, h->d_state2);
                 launch_reduce_rows(h->partials.as<double>(), grid, h->d_state, send, 0, h->stream);
                 if (g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream) != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }

@@ -114,7 +114,8 @@ void residual_set_cu_count(int n);        // compute units of the device (256 on
 // chained single-scan iteration: previous launch's reduction + step in every block's prologue, then the residual pass
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
-                           const EvalParams& ep, double* partials, int grid, int linked, hipStream_t s);
+                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, hipStream_t s);
+// (init_state: host pointer or nullptr; given, the launch starts from a fresh state at that pose instead of reading st_in)
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, int linked, hipStream_t s);

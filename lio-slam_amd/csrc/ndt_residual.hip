@@ -17,6 +17,7 @@
 #include "ndt_internal.h"
 
 #include <atomic>
+#include <cstddef>
 #include "ndt_kernels.h"
 
 #define RES_THREADS 256    // batched launches: several blocks per CU overlap their tails
@@ -276,12 +277,15 @@ __device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp);
 __device__ __forceinline__ double hb_entry(const double* R, const double* raw, int e);
 __device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
 
+struct InitPose { double Rt[12]; int use; };
+static_assert(offsetof(GnState, R) == 0 && offsetof(GnState, t) == 72, "InitPose fills the first twelve words of GnState");
+
 template <int K, bool LINKED>
 __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __restrict__ xs, const float* __restrict__ ys,
                                                                 const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
                                                                 const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st_in,
                                                                 GnState* __restrict__ st_out, const double* __restrict__ prev_partials, int n_prev,
-                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials) {
+                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init) {
     static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
     __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
@@ -289,7 +293,10 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     int i = blockIdx.x * RES1_THREADS + threadIdx.x;
     float xf = 0.f, yf = 0.f, zf = 0.f;
     if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
-    if (threadIdx.x < ST_WORDS) ((double*)&sst)[threadIdx.x] = ((const double*)st_in)[threadIdx.x];
+    // the state: from st_in, or (first launch of an align) a fresh one at the pose that came as a kernel argument,
+    // which saves the host-to-device copy in front of the loop (R[9], t[3] are the first twelve words; the rest is zero)
+    if (threadIdx.x < ST_WORDS)
+        ((double*)&sst)[threadIdx.x] = init.use ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : ((const double*)st_in)[threadIdx.x];
     if (n_prev > 0) reduce_rows32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
     else __syncthreads();
     if (n_prev > 0) {          // (uniform) world-frame sums -> H, b: one lane per entry; sst still holds the pose the rows were computed at
@@ -421,8 +428,14 @@ void launch_residual(const float* x, const float* y, const float* z, int n, cons
 
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
-                           const EvalParams& ep, double* partials, int grid, int linked, hipStream_t s) {
-#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials)
+                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, hipStream_t s) {
+    InitPose init{};
+    if (init_state) {
+        for (int j = 0; j < 9; ++j) init.Rt[j] = init_state->R[j];
+        for (int j = 0; j < 3; ++j) init.Rt[9 + j] = init_state->t[j];
+        init.use = 1;
+    }
+#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init)
     if (ep.nearby == 7) { if (linked) LAUNCH(7, true); else LAUNCH(7, false); }
     else LAUNCH(1, false);
 #undef LAUNCH
