@@ -30,7 +30,7 @@ struct Pose { double R[9]; double t[3]; };
 template <int K>
 __device__ __forceinline__ unsigned gate_and_sum(const Payload* pay, const uint32_t* fs, const double* q, const int32_t* c,
                                                  const EvalParams& ep, double* S, double* g, double* acc) {
-    unsigned hitmask = 0;
+    unsigned hitmask = 0, voxmask = 0;
 #pragma unroll
     for (int pr = 0; pr < K; ++pr) {
         const int dx = pr == 1 ? -1 : pr == 2 ? 1 : 0, dy = pr == 3 ? -1 : pr == 4 ? 1 : 0, dz = pr == 5 ? -1 : pr == 6 ? 1 : 0;
@@ -47,16 +47,17 @@ __device__ __forceinline__ unsigned gate_and_sum(const Payload* pay, const uint3
         const double chi2 = fma(e2, g2, fma(e1, g1, e0 * g0));
         const bool ok = vox && chi2 <= ep.outlier_th;               // false for NaN
         hitmask |= ok ? 1u << pr : 0u;
+        voxmask |= vox ? 1u << pr : 0u;
         // w is exactly 0 or 1 and every operand is finite (payloads of valid voxels are finite, slot 0 stands in for
         // misses), so fma(w, v, s) equals the plain s + v when the residual is accepted and s otherwise
         const double w = ok ? 1.0 : 0.0;
-        acc[ACC_HITS] += vox ? 1.0 : 0.0;
         S[0] = fma(w, i00, S[0]); S[1] = fma(w, i01, S[1]); S[2] = fma(w, i02, S[2]);
         S[3] = fma(w, i11, S[3]); S[4] = fma(w, i12, S[4]); S[5] = fma(w, i22, S[5]);
         g[0] = fma(w, g0, g[0]); g[1] = fma(w, g1, g[1]); g[2] = fma(w, g2, g[2]);
         acc[ACC_CHI2] = fma(w, chi2, acc[ACC_CHI2]);
-        acc[ACC_NEFF] += w;
     }
+    acc[ACC_HITS] += (double)__popc(voxmask);                        // the counters: small integers, exact either way
+    acc[ACC_NEFF] += (double)__popc(hitmask);
     return hitmask;
 }
 
