@@ -40,14 +40,14 @@ struct PclPass {
 
 // the three cells of a row once their table entries are known: radius test, Magnusson weight, neighbour sums
 __device__ __forceinline__ void pcl_row_sums(const PclPass& pp, const float* qf, const int32_t* c, int32_t n1, int32_t n2, const uint32_t* fs,
-                                             const Payload* pay, double* G, double* S, double* Mm, double& score, double& nb, double& nvox) {
+                                             const Payload* pay, double* G, double* S, double* Mm, double& score, unsigned& nb, unsigned& nvox) {
     const double res = pp.kp.res_d;
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) {
         const int32_t n0 = c[0] + pr - 1;
         const bool vox = fs[pr] != SLOT_NONE && pay[pr].a.x != 0;
         if (!__any(vox)) continue;                       // no lane of the wave has a voxel in this cell
-        nvox += vox ? 1.0 : 0.0;
+        nvox += vox ? 1u : 0u;
         const float o0 = __int_as_float(pay[pr].a.z), o1 = __int_as_float(pay[pr].a.w), o2 = pay[pr].b.x;
         // radius search on the centroid cloud: float32 centroid, float32 squared distance, strictly inside
         const float c0 = (float)((double)n0 * res + (double)o0), c1 = (float)((double)n1 * res + (double)o1), c2 = (float)((double)n2 * res + (double)o2);
@@ -55,7 +55,7 @@ __device__ __forceinline__ void pcl_row_sums(const PclPass& pp, const float* qf,
         const float dist2 = (f0 * f0 + f1 * f1) + f2 * f2;
         const bool nbr = vox && dist2 < pp.r2f;
         if (!__any(nbr)) continue;                       // ... or none within the radius: skip the float64 part (~60 instructions)
-        nb += nbr ? 1.0 : 0.0;
+        nb += nbr ? 1u : 0u;
         const double i22 = __int_as_float(pay[pr].a.y), i00 = pay[pr].b.y, i01 = pay[pr].b.z, i02 = pay[pr].b.w, i11 = pay[pr].c.x, i12 = pay[pr].c.y;
         const double x0 = ((double)qf[0] - (double)n0 * res) - (double)o0;
         const double x1 = ((double)qf[1] - (double)n1 * res) - (double)o1;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void pcl_row_sums(const PclPass& pp, const float* qf,
 // the kernel at two waves per SIMD; nine at a time need 386 registers.
 __device__ __forceinline__ void pcl_row(const PclPass& pp, const float* qf, const int32_t* c, int dy, int dz, const int64_t* __restrict__ keys,
                                           const VoxSlot* __restrict__ slots, uint32_t mask, bool point_ok, double* G, double* S, double* Mm,
-                                          double& score, double& nb, double& nvox) {
+                                          double& score, unsigned& nb, unsigned& nvox) {
     int64_t want[3];
     uint32_t s0[3];
     Key2 ka[3], kb[3];
@@ -150,7 +150,7 @@ __device__ __forceinline__ RowProbe pcl_row_issue(const int32_t* c, int row, con
 }
 __device__ __forceinline__ void pcl_row_finish(const PclPass& pp, const float* qf, const int32_t* c, const RowProbe& r, const int64_t* __restrict__ keys,
                                                const VoxSlot* __restrict__ slots, uint32_t mask, double* G, double* S, double* Mm,
-                                               double& score, double& nb, double& nvox) {
+                                               double& score, unsigned& nb, unsigned& nvox) {
     const int64_t want = r.want;
     const bool m0 = r.ka.x == want, m1 = r.ka.y == want, m2 = r.kb.x == want, m3 = r.kb.y == want;
     const bool e0 = r.ka.x == NDT_KEY_EMPTY, e1 = r.ka.y == NDT_KEY_EMPTY, e2 = r.kb.x == NDT_KEY_EMPTY, e3 = r.kb.y == NDT_KEY_EMPTY;
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(PCL_THREADS) void k_pcl_pass(const float* __restric
         bool ok = i < n && isfinite(qf[0]) && isfinite(qf[1]) && isfinite(qf[2]);
         ok = ok && ndt_target_cell(pp.kp, qf[0], qf[1], qf[2], c);
         if (!ok) { c[0] = c[1] = c[2] = 0; qf[0] = qf[1] = qf[2] = 0.f; x = y = z = 0.f; }   // nothing non-finite may reach the sums
-        double G[3] = {0, 0, 0}, S[6] = {0, 0, 0, 0, 0, 0}, Mm[6] = {0, 0, 0, 0, 0, 0}, score = 0.0, nb = 0.0, nvox = 0.0;
+        double G[3] = {0, 0, 0}, S[6] = {0, 0, 0, 0, 0, 0}, Mm[6] = {0, 0, 0, 0, 0, 0}, score = 0.0;
+        unsigned nb = 0, nvox = 0;                       // integer counters: no float64 chains through the 27 cells
 #pragma unroll 1
         for (int row = 0; row < 9 && !LINKED; ++row) pcl_row(pp, qf, c, row % 3 - 1, row / 3 - 1, keys, slots, mask, ok, G, S, Mm, score, nb, nvox);
         if (LINKED) {
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(PCL_THREADS) void k_pcl_pass(const float* __restric
                 pcl_row_finish(pp, qf, c, cur, keys, slots, mask, G, S, Mm, score, nb, nvox);
             }
         }
-        acc[PCL_ACC_NB] += nb;
-        acc[PCL_ACC_VOX] += nvox;
-        if (!__any(nb != 0.0)) continue;
+        acc[PCL_ACC_NB] += (double)nb;
+        acc[PCL_ACC_VOX] += (double)nvox;
+        if (!__any(nb != 0u)) continue;
         if (GRAD) acc[PCL_ACC_SCORE] += score;
         // point Jacobian (computePointDerivatives): columns 3..5 of J_E from the ORIGINAL point
         const double px = x, py = y, pz = z;
