@@ -239,6 +239,25 @@ __device__ __forceinline__ unsigned point_terms_linked(const Pose& P, float xf, 
     return point_terms_from_probe(P, xf, yf, zf, pr, keys, slots, mask, ep, acc, cell_key);
 }
 
+// A lane's points i, i + stride, ... < hi through the linked NEARBY7 path with one software-pipeline stage: the centre keys
+// of the NEXT point are requested before the current point is worked on, so a lane waits for three dependent round trips
+// per point instead of four.  (xf, yf, zf) = point i, already loaded.
+__device__ __forceinline__ void lane_points_linked(const Pose& P, const float* __restrict__ xs, const float* __restrict__ ys,
+                                                   const float* __restrict__ zs, int64_t i, int64_t hi, int64_t stride, float xf, float yf, float zf,
+                                                   const int64_t* __restrict__ keys, const VoxSlot* __restrict__ slots, uint32_t mask,
+                                                   const EvalParams& ep, double* acc) {
+    CentreProbe pr = centre_probe(P, xf, yf, zf, keys, mask, ep);
+    while (i < hi) {
+        const int64_t in = i + stride;
+        float xn = 0.f, yn = 0.f, zn = 0.f;
+        if (in < hi) { xn = xs[in]; yn = ys[in]; zn = zs[in]; }
+        const CentreProbe prn = centre_probe(P, xn, yn, zn, keys, mask, ep);
+        int64_t ck;
+        point_terms_from_probe(P, xf, yf, zf, pr, keys, slots, mask, ep, acc, &ck);
+        pr = prn; xf = xn; yf = yn; zf = zn; i = in;
+    }
+}
+
 template <int K, bool CELLS, bool LINKED>
 __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restrict__ xs, const float* __restrict__ ys,
                                                           const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
@@ -258,13 +277,17 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
     double acc[ACC_N];
 #pragma unroll
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
-    while (i < n) {
-        int64_t ck;
-        const unsigned hm = LINKED ? point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck)
-                                   : point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
-        if (CELLS) { keys_out[i] = ck; mask_out[i] = (uint8_t)hm; }
-        i += gridDim.x * RES1_THREADS;
-        if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    if (LINKED && !CELLS) {
+        lane_points_linked(P, xs, ys, zs, i, n, (int64_t)gridDim.x * RES1_THREADS, xf, yf, zf, keys, slots, mask, ep, acc);
+    } else {
+        while (i < n) {
+            int64_t ck;
+            const unsigned hm = LINKED ? point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck)
+                                       : point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
+            if (CELLS) { keys_out[i] = ck; mask_out[i] = (uint8_t)hm; }
+            i += gridDim.x * RES1_THREADS;
+            if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+        }
     }
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
 }
@@ -321,6 +344,8 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     double acc[ACC_N];
 #pragma unroll
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
+    // (the plain loop: with the prologue's state this kernel has no registers left for lane_points_linked's extra stage —
+    // it spills 18 and an align of 117 594 points takes 0.165 ms instead of 0.120)
     while (i < n) {
         int64_t ck;
         if (LINKED) point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
@@ -357,19 +382,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 #pragma unroll
     for (int j = 0; j < ACC_N; ++j) acc[j] = 0.0;
     if (LINKED) {
-        // one software-pipeline stage: the centre keys of the NEXT point are requested before the current point is worked
-        // on, so a lane waits for three dependent round trips per point instead of four
-        const int64_t stride = (int64_t)gridDim.x * RES_THREADS;
-        CentreProbe pr = centre_probe(P, xf, yf, zf, keys, mask, ep);
-        while (i < hi) {
-            const int64_t in = i + stride;
-            float xn = 0.f, yn = 0.f, zn = 0.f;
-            if (in < hi) { xn = xs[in]; yn = ys[in]; zn = zs[in]; }
-            const CentreProbe prn = centre_probe(P, xn, yn, zn, keys, mask, ep);
-            int64_t ck;
-            point_terms_from_probe(P, xf, yf, zf, pr, keys, slots, mask, ep, acc, &ck);
-            pr = prn; xf = xn; yf = yn; zf = zn; i = in;
-        }
+        lane_points_linked(P, xs, ys, zs, i, hi, (int64_t)gridDim.x * RES_THREADS, xf, yf, zf, keys, slots, mask, ep, acc);
     } else {
         while (i < hi) {
             int64_t ck;
