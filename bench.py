@@ -169,7 +169,18 @@ def main():
         # mode has one, is RCCL inside libndt_mi355.so on the handle's own stream
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo's C++ layer announces its connections on stdout; rank 0's stdout is for the ONE JSON line, so the
+        # rendezvous runs with file descriptor 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
         if ndev:
             local %= ndev                         # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
