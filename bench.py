@@ -16,6 +16,7 @@ the ranks with an RCCL all-reduce of the 29 H/b/chi2/n terms per iteration (conf
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -28,6 +29,21 @@ sys.path.insert(0, ROOT)
 
 DEFAULT_BATCH = 64      # pairs per step per GPU: configs[4] replays 4096 pairs over 8 GPUs (512 per GPU), a step is a slice of that
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 pointed at stderr for the duration: native libraries (gloo, RCCL) that announce themselves on
+    stdout must not get in front of the one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def algorithmic_bytes_per_point(k, h):
@@ -171,16 +187,9 @@ def main():
         import torch.distributed as dist
         # gloo's C++ layer announces its connections on stdout; rank 0's stdout is for the ONE JSON line, so the
         # rendezvous runs with file descriptor 1 pointed at stderr
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
         ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
         if ndev:
             local %= ndev                         # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
@@ -288,9 +297,10 @@ def main():
         build_rl = build_roofline(n_map, n_vox, rb_passes, rb_ms); del big_map
         lo, hi = shard_range(len(scan_all), rank, world)
         if use_dist:
-            ids = [la.NDT.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ndt.comm_init(rank, world, ids[0])
+            with stdout_to_stderr():                             # RCCL prints its version banner on stdout
+                ids = [la.NDT.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ndt.comm_init(rank, world, ids[0])
         ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
         pts_rank = float(ndt.source_size())
         step = lambda: ndt.align(guess)
