@@ -7,6 +7,7 @@ the call surface the reference uses on its `pcl::NormalDistributionsTransform nd
 There is no CPU fallback: if the HIP library is missing or no GPU is present, construction
 raises.
 """
+import collections.abc
 import ctypes as C
 import os
 import subprocess
@@ -181,16 +182,31 @@ def _points(pts):
     return a, a.ctypes.data, a.shape[0], a.shape[1] * 4
 
 
+class BatchResults(collections.abc.Sequence):
+    """Results of a batched align: behaves like a list of result dicts (same keys as align(), plus 'status'), built per
+    item on access — building a few thousand dicts per call would cost a replay loop in Python more time than the GPU
+    spends aligning.  `.array` is the structured ndt_result array itself."""
+
+    def __init__(self, res):
+        self.array = res
+        n = len(res)
+        self._T = res["T"].reshape(n, 4, 4).transpose(0, 2, 1)
+        self._H = res["H"].reshape(n, 6, 6)
+
+    def __len__(self):
+        return len(self.array)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        r = self.array[i]
+        st = int(r["status"])
+        return dict(rc=st, status=st, T=self._T[i], H=self._H[i], b=r["b"], chi2=float(r["chi2"]), n_effective=int(r["n_effective"]),
+                    iterations=int(r["iterations"]), converged=bool(r["converged"]), last_dx_norm=float(r["last_dx_norm"]))
+
+
 def _unpack_results(res):
-    """structured ndt_result array -> list of result dicts (vectorised: a replay loop in Python would otherwise spend
-    more time here than the GPU spends aligning)"""
-    n_pairs = len(res)
-    T = res["T"].reshape(n_pairs, 4, 4).transpose(0, 2, 1)
-    H = res["H"].reshape(n_pairs, 6, 6)
-    return [dict(rc=int(st), status=int(st), T=T[i], H=H[i], b=res["b"][i], chi2=float(res["chi2"][i]),
-                 n_effective=int(res["n_effective"][i]), iterations=int(res["iterations"][i]),
-                 converged=bool(res["converged"][i]), last_dx_norm=float(res["last_dx_norm"][i]))
-            for i, st in enumerate(res["status"])]
+    return BatchResults(res)
 
 
 class NDTGroup:
