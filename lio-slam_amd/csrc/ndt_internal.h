@@ -50,6 +50,7 @@ struct SortedCells {       // result of sort_points_by_cell
     SortKeyMap km = {};
     int passes = 0;
     const uint64_t* sorted_keys = nullptr;
+    const uint32_t* sorted_vals = nullptr;  // index of each sorted point in the unsorted arrays (w.tx/ty/tz)
 };
 
 struct MapBuildCfg {

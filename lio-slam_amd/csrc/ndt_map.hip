@@ -452,7 +452,7 @@ __global__ void k_big_list(const uint32_t* seg_start, uint32_t nseg, uint32_t bi
     big_pos[g] = pos;
 }
 __global__ __launch_bounds__(BIG_THREADS) void k_big_sums(const uint32_t* big_list, const uint32_t* big_count, const uint64_t* sk, const uint32_t* seg_start,
-                                                          const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg, double* big_sums) {
+                                                          const uint32_t* __restrict__ sv, const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg, double* big_sums) {
     if (blockIdx.x >= *big_count) return;
     __shared__ double sm[BIG_THREADS / 64][9];
     const uint32_t g = big_list[blockIdx.x];
@@ -467,7 +467,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_big_sums(const uint32_t* big_li
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + u * BIG_THREADS;
             const bool in = i < e;
-            x[u] = in ? tx[i] : 0.f; y[u] = in ? ty[i] : 0.f; z[u] = in ? tz[i] : 0.f;
+            const uint32_t j = in ? sv[i] : 0u;          // the point's place in the unsorted arrays
+            x[u] = in ? tx[j] : 0.f; y[u] = in ? ty[j] : 0.f; z[u] = in ? tz[j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_big_sums(const uint32_t* big_li
 }
 
 template <int SEG_LANES>
-__global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg,
+__global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const uint32_t* seg_start, uint32_t nseg, const uint32_t* __restrict__ sv,
                                                        const float* tx, const float* ty, const float* tz, SortKeyMap km, MapBuildCfg cfg,
                                                        int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
                                                        uint32_t* entry_flag, uint32_t* seg_slot, const uint32_t* big_pos, const double* big_sums) {
@@ -516,7 +517,8 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t e_loop = bp == 0xFFFFFFFFu ? e : s;          // a big segment was summed by k_big_sums
     for (uint32_t i = s + l; i < e_loop; i += SEG_LANES) {
-        double d0 = (double)tx[i] - org[0], d1 = (double)ty[i] - org[1], d2 = (double)tz[i] - org[2];
+        const uint32_t j = sv[i];
+        double d0 = (double)tx[j] - org[0], d1 = (double)ty[j] - org[1], d2 = (double)tz[j] - org[2];
         a[0] += d0; a[1] += d1; a[2] += d2;
         a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
         a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
@@ -868,10 +870,12 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
         HIP_TRY(w.seg_start.ensure((n_valid + 1) * 4));      // nseg <= n_valid: no read-back needed to size it
     }
     k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
-    HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
-    k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
+    if (zyx_order) {     // (the downsample path reads the points in sorted order; the map merge gathers through sorted_vals itself)
+        HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
+        k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
+    }
     HIP_TRY(hipGetLastError());
-    out->n_valid = n_valid; out->nseg = nseg; out->d_nseg = d_nseg; out->km = km; out->passes = P; out->sorted_keys = ka;
+    out->n_valid = n_valid; out->nseg = nseg; out->d_nseg = d_nseg; out->km = km; out->passes = P; out->sorted_keys = ka; out->sorted_vals = va;
     out->bbox_cells = 1;
     for (int j = 0; j < 3; ++j) out->bbox_cells *= (uint64_t)((int64_t)misc[3 + j] - misc[j] + 1);
     return NDT_OK;
@@ -898,15 +902,15 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     uint32_t* big_count = (uint32_t*)(w.misc.as<int32_t>() + 12);
     k_big_list<<<(nseg + 255) / 256, 256, 0, s>>>(segs, nseg, big, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
     if (big_ub)
-        k_big_sums<<<(unsigned)big_ub, BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, sc.sorted_keys, segs, w.gx.as<float>(), w.gy.as<float>(),
-                                                           w.gz.as<float>(), sc.km, cfg, w.big_sums.as<double>());
+        k_big_sums<<<(unsigned)big_ub, BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, sc.sorted_keys, segs, sc.sorted_vals, w.tx.as<float>(), w.ty.as<float>(),
+                                                           w.tz.as<float>(), sc.km, cfg, w.big_sums.as<double>());
     if (wide) {
         const unsigned nbs = (unsigned)(((size_t)nseg * 64 + 255) / 256);
-        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.keys,
+        k_segment_merge<64><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.sorted_vals, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), sc.km, cfg, m.keys,
                                                 m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>(), seg_slot, w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
     } else {
         const unsigned nbs = (unsigned)(((size_t)nseg * 8 + 255) / 256);
-        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>(), sc.km, cfg, m.keys,
+        k_segment_merge<8><<<nbs, 256, 0, s>>>(sc.sorted_keys, segs, nseg, sc.sorted_vals, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), sc.km, cfg, m.keys,
                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>(), seg_slot, w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
     }
     k_finalize_segments<<<(nseg + 255) / 256, 256, 0, s>>>(seg_slot, nseg, cfg, m.slots, m.counts, m.mean, m.cov);
