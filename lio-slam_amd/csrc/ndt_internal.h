@@ -64,9 +64,9 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s);
 void map_free(VoxelMap& m);
 hipError_t map_clear(VoxelMap& m, hipStream_t s);
 struct MapWork {
-    DevBuf raw, tx, ty, tz, gx, gy, gz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc, big_pos, big_list, big_sums;
+    DevBuf raw, tx, ty, tz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc, big_pos, big_list, big_sums;
     void release() {
-        DevBuf* all[] = {&raw, &tx, &ty, &tz, &gx, &gy, &gz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums};
+        DevBuf* all[] = {&raw, &tx, &ty, &tz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums};
         for (DevBuf* b : all) b->release();
     }
 };

@@ -426,13 +426,6 @@ __device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3],
     sl->valid = valid;
 }
 
-// world points gathered into sorted order, so the per-voxel sums read contiguous lanes
-__global__ void k_gather_sorted(const uint32_t* sv, size_t n, const float* tx, const float* ty, const float* tz, float* gx, float* gy, float* gz) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t idx = sv[i];
-    gx[i] = tx[idx]; gy[i] = ty[idx]; gz[i] = tz[idx];
-}
 
 // One SEG_LANES-lane group per segment (= one voxel of the batch): strided sums in voxel-local float64
 // coordinates over the sorted points, xor-tree over the group, then lane 0 claims / finds the hash slot and merges.
@@ -599,15 +592,15 @@ __global__ __launch_bounds__(256) void k_finalize_segments(const uint32_t* seg_s
 // pcl::VoxelGrid centroid (src/slam/src/process.cc:68-73): mean of the cell's points, float64 sum in sorted order,
 // one rounding to float32; output row = segment index (cells in PCL's index order when sorted z,y,x)
 template <int SEG_LANES>
-__global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_start, const uint32_t* d_nseg, const float* gx, const float* gy,
-                                                          const float* gz, float* ox, float* oy, float* oz) {
+__global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_start, const uint32_t* d_nseg, const uint32_t* __restrict__ sv, const float* gx,
+                                                          const float* gy, const float* gz, float* ox, float* oy, float* oz) {
     const uint32_t nseg = *d_nseg;      // the launch covers the upper bound n_valid; groups past nseg have nothing to do
     uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / SEG_LANES;
     const int l = threadIdx.x % SEG_LANES;
     uint32_t s = 0, e = 0;
     if (g < nseg) { s = seg_start[g]; e = seg_start[g + 1]; }
     double a[3] = {0, 0, 0};
-    for (uint32_t i = s + l; i < e; i += SEG_LANES) { a[0] += (double)gx[i]; a[1] += (double)gy[i]; a[2] += (double)gz[i]; }
+    for (uint32_t i = s + l; i < e; i += SEG_LANES) { const uint32_t j = sv[i]; a[0] += (double)gx[j]; a[1] += (double)gy[j]; a[2] += (double)gz[j]; }
 #pragma unroll
     for (int o = SEG_LANES / 2; o >= 1; o >>= 1)
 #pragma unroll
@@ -777,7 +770,7 @@ static int finish_entries(VoxelMap& m, MapWork& w, const uint64_t* sorted_keys, 
 }
 
 // Stage 1 of every cloud ingest: (optional transform,) cell of every point, LSD radix sort of (cell, index),
-// segments (= cells) and the points gathered into sorted order (w.gx/gy/gz).  pts: AoS records in host or device
+// segments (= cells); the per-cell sums read the points through the sorted index (sorted_vals), so no sorted copy is made.  pts: AoS records in host or device
 // memory, or (stride == 0) three device SoA arrays passed through pts / soa_y / soa_z.
 int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
                         const double* R, const double* t, bool zyx_order, bool host_nseg, hipStream_t s, SortedCells* out, std::string& err) {
@@ -870,10 +863,6 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
         HIP_TRY(w.seg_start.ensure((n_valid + 1) * 4));      // nseg <= n_valid: no read-back needed to size it
     }
     k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
-    if (zyx_order) {     // (the downsample path reads the points in sorted order; the map merge gathers through sorted_vals itself)
-        HIP_TRY(w.gx.ensure(n_valid * 4)); HIP_TRY(w.gy.ensure(n_valid * 4)); HIP_TRY(w.gz.ensure(n_valid * 4));
-        k_gather_sorted<<<nbv, 256, 0, s>>>(va, n_valid, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(), w.gx.as<float>(), w.gy.as<float>(), w.gz.as<float>());
-    }
     HIP_TRY(hipGetLastError());
     out->n_valid = n_valid; out->nseg = nseg; out->d_nseg = d_nseg; out->km = km; out->passes = P; out->sorted_keys = ka; out->sorted_vals = va;
     out->bbox_cells = 1;
@@ -931,11 +920,11 @@ int downsample_points(MapWork& w, const KeyParams& leaf_kp, const void* pts, siz
     // lanes per cell from what is known without a read-back: at least n_valid / bbox_cells points per cell on average
     const uint64_t cells_ub = std::min<uint64_t>(sc.bbox_cells, sc.n_valid);
     if (sc.n_valid / cells_ub >= 24) {
-        k_segment_centroid<64><<<(unsigned)((cells_ub * 64 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, w.gx.as<float>(),
-                                                                                     w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+        k_segment_centroid<64><<<(unsigned)((cells_ub * 64 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, sc.sorted_vals, w.tx.as<float>(),
+                                                                                     w.ty.as<float>(), w.tz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
     } else {
-        k_segment_centroid<8><<<(unsigned)((cells_ub * 8 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, w.gx.as<float>(),
-                                                                                   w.gy.as<float>(), w.gz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
+        k_segment_centroid<8><<<(unsigned)((cells_ub * 8 + 255) / 256), 256, 0, s>>>(w.seg_start.as<uint32_t>(), sc.d_nseg, sc.sorted_vals, w.tx.as<float>(),
+                                                                                   w.ty.as<float>(), w.tz.as<float>(), ox.as<float>(), oy.as<float>(), oz.as<float>());
     }
     HIP_TRY(hipGetLastError());
     *d_n_out = sc.d_nseg;
