@@ -8,16 +8,25 @@
 // PointCloudFactor, src/slam/include/factor.h:220-269) and addTargetCloud() (incremental keyframe merge in place
 // of the rebuild at process.cc:134-147).
 //
-// No PCL / Eigen types are needed: clouds are anything with data()/size() of records whose first 12 bytes are
-// float x,y,z (pcl::PointCloud<P>::points is a std::vector<P>; use cloud.points) and matrices are plain
-// column-major arrays, the memory layout of Eigen::Matrix4f / Matrix4d.  With Eigen present:
-//   Eigen::Matrix4f guess = state.getTransform();
-//   ndt_.align(guess.data());  Eigen::Map<const Eigen::Matrix4f>(ndt_.getFinalTransformationF().data());
+// No PCL / Eigen headers are needed, and the reference's call sites compile unchanged against it:
+//   clouds   : anything with data()/size() of records whose first 12 bytes are float x,y,z — pcl::PointCloud<P> has both
+//              (PCL >= 1.11), so has std::vector<P>; shared pointers to either are accepted (process.cc:78,87,147);
+//   matrices : align(out, guess) takes any fixed 4x4 type with data() over 16 column-major floats or doubles, by value or
+//              reference (Eigen::Matrix4f at process.cc:94), and getFinalTransformation() returns a value that converts to
+//              any such type (`ndt_pose_ = ndt_.getFinalTransformation();`, process.cc:95) and is itself a
+//              std::array<double,16>.  Raw `const float*` / `const double*` column-major pointers work too.
+// Error behaviour follows PCL's: the eight reference methods and the other void methods never throw — a failure is
+// printed on stderr (PCL_ERROR's role), recorded in status() / lastError(), and clears hasConverged(); the reference
+// checks none of it (process.cc:94-95).  setThrowOnError(true) turns every recorded failure into an ndt_mi355::Error.
+// Methods that return data (saveMap, alignBatch) always throw on failure.
 #pragma once
 #include <array>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ndt_mi355.h"
@@ -27,6 +36,30 @@ namespace ndt_mi355 {
 struct Error : std::runtime_error {
     int code;
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+namespace detail {
+// a 4x4 matrix type: has data() over float or double (Eigen::Matrix4f / Matrix4d, std::array<float,16>, ...)
+template <class M, class = void> struct matrix_scalar { using type = void; };
+template <class M>
+struct matrix_scalar<M, std::void_t<decltype(std::declval<const M&>().data())>> {
+    using type = std::remove_cv_t<std::remove_pointer_t<decltype(std::declval<const M&>().data())>>;
+};
+template <class M>
+inline constexpr bool is_matrix_v = std::is_same_v<typename matrix_scalar<M>::type, float> || std::is_same_v<typename matrix_scalar<M>::type, double>;
+}  // namespace detail
+
+// What getFinalTransformation() returns: a column-major double[16] (std::array) that converts to any 4x4 matrix type
+// with a default constructor and a mutable data() over 16 floats or doubles — `Eigen::Matrix4f m = ...;` and
+// `ndt_pose_ = ndt_.getFinalTransformation();` (process.cc:95) compile as written against PCL.
+struct FinalTransformation : std::array<double, 16> {
+    template <class M, class = std::enable_if_t<detail::is_matrix_v<M> && !std::is_base_of_v<std::array<double, 16>, M>>>
+    operator M() const {
+        M m;
+        using S = typename detail::matrix_scalar<M>::type;
+        for (int i = 0; i < 16; ++i) m.data()[i] = (S)(*this)[i];
+        return m;
+    }
 };
 
 template <typename PointSource, typename PointTarget = PointSource>
@@ -47,6 +80,9 @@ class NormalDistributionsTransform {
     ~NormalDistributionsTransform() { ndt_destroy(h_); }
     NormalDistributionsTransform(const NormalDistributionsTransform&) = delete;
     NormalDistributionsTransform& operator=(const NormalDistributionsTransform&) = delete;
+
+    // failures are recorded (status(), lastError()) and printed; true: they are thrown as ndt_mi355::Error as well
+    void setThrowOnError(bool on) { throw_ = on; }
 
     // --- the reference's setters (process.cc:373-376)
     void setResolution(float r) { cfg_.resolution = r; reconfigure(); }
@@ -69,20 +105,26 @@ class NormalDistributionsTransform {
     const ndt_config& config() const { return cfg_; }
 
     // --- clouds.  The engine copies into HBM; the caller's buffer is free on return (PCL keeps the pointer).
-    template <class Cloud> void setInputTarget(const Cloud& c) { check(ndt_set_target(handle(), c.data(), c.size(), sizeof(PointTarget))); }
+    template <class Cloud> void setInputTarget(const Cloud& c) {
+        if (ndt_handle* h = handle("setInputTarget")) note("setInputTarget", ndt_set_target(h, c.data(), c.size(), sizeof(PointTarget)));
+    }
     template <class Cloud> void setInputTarget(const std::shared_ptr<Cloud>& c) { setInputTarget(*c); }
     template <class Cloud> void addTargetCloud(const Cloud& c, const double* T_colmajor = nullptr) {
-        check(ndt_add_target(handle(), c.data(), c.size(), sizeof(PointTarget), T_colmajor));
+        if (ndt_handle* h = handle("addTargetCloud")) note("addTargetCloud", ndt_add_target(h, c.data(), c.size(), sizeof(PointTarget), T_colmajor));
     }
-    template <class Cloud> void setInputSource(const Cloud& c) { check(ndt_set_source(handle(), c.data(), c.size(), sizeof(PointSource))); }
+    template <class Cloud> void setInputSource(const Cloud& c) {
+        if (ndt_handle* h = handle("setInputSource")) note("setInputSource", ndt_set_source(h, c.data(), c.size(), sizeof(PointSource)));
+    }
     template <class Cloud> void setInputSource(const std::shared_ptr<Cloud>& c) { setInputSource(*c); }
 
     // --- align.  PCL's first argument (`output`, a scratch cloud the reference never reads, process.cc:92) is
     // accepted and left untouched.  Errors do not throw here (PCL prints and clears converged_; the reference
     // ignores both, process.cc:94-95): status() tells.
     void align(const double* guess_colmajor) {
+        ndt_handle* h = handle("align");
+        if (!h) { res_ = ndt_result{}; res_.status = status_; return; }
         if (pcl_mode_) {
-            status_ = ndt_pcl_align(handle(), &pcl_, guess_colmajor, &pres_);
+            status_ = ndt_pcl_align(h, &pcl_, guess_colmajor, &pres_);
             res_ = ndt_result{};
             for (int i = 0; i < 16; ++i) res_.T[i] = pres_.T[i];
             for (int i = 0; i < 36; ++i) res_.H[i] = -pres_.hessian[i];   // the score is maximised: -Hessian is the curvature
@@ -90,10 +132,12 @@ class NormalDistributionsTransform {
             res_.iterations = pres_.iterations;
             res_.converged = status_ == NDT_OK ? pres_.converged : 0;
             res_.status = status_;
+            note("align", status_);
             return;
         }
-        status_ = ndt_align(handle(), guess_colmajor, &res_);
+        status_ = ndt_align(h, guess_colmajor, &res_);
         if (status_ != NDT_OK) res_.converged = 0;
+        note("align", status_);
     }
     void align(const float* guess_colmajor) {
         double g[16];
@@ -101,8 +145,14 @@ class NormalDistributionsTransform {
         align(g);
     }
     template <class Cloud, class Scalar> void align(Cloud& /*output*/, const Scalar* guess_colmajor) { align(guess_colmajor); }
+    // `ndt_.align(*output, ndt_pose_)` with an Eigen::Matrix4f (process.cc:94): any matrix type with data() over 16
+    // column-major floats or doubles, taken by reference or by value
+    template <class Cloud, class M, class = std::enable_if_t<detail::is_matrix_v<M>>>
+    void align(Cloud& /*output*/, const M& guess) { align(guess.data()); }
+    template <class M, class = std::enable_if_t<detail::is_matrix_v<M>>>
+    void align(const M& guess) { align(guess.data()); }
 
-    Matrix4d getFinalTransformation() const { Matrix4d m; for (int i = 0; i < 16; ++i) m[i] = res_.T[i]; return m; }
+    FinalTransformation getFinalTransformation() const { FinalTransformation m; for (int i = 0; i < 16; ++i) m[i] = res_.T[i]; return m; }
     Matrix4f getFinalTransformationF() const { Matrix4f m; for (int i = 0; i < 16; ++i) m[i] = (float)res_.T[i]; return m; }
     bool hasConverged() const { return res_.converged != 0; }
     int getFinalNumIteration() const { return res_.iterations; }
@@ -115,18 +165,23 @@ class NormalDistributionsTransform {
     }
     // Scan pre-processing and keyframe step on the device (process.cc:62-73,87 and 134-147): no host round trip
     template <class Cloud> void setInputSourceRaw(const Cloud& c, float leaf, const double* T_extrinsic_colmajor = nullptr) {
-        check(ndt_set_source_downsampled(handle(), c.data(), c.size(), sizeof(PointSource), leaf, T_extrinsic_colmajor));
+        if (ndt_handle* h = handle("setInputSourceRaw"))
+            note("setInputSourceRaw", ndt_set_source_downsampled(h, c.data(), c.size(), sizeof(PointSource), leaf, T_extrinsic_colmajor));
     }
-    void addSourceToTarget(const double* T_colmajor) { check(ndt_add_target_from_source(handle(), T_colmajor)); }
+    void addSourceToTarget(const double* T_colmajor) {
+        if (ndt_handle* h = handle("addSourceToTarget")) note("addSourceToTarget", ndt_add_target_from_source(h, T_colmajor));
+    }
     // Voxel-map serialisation (ndt_map_save / ndt_map_load): e.g. to resume a session without the keyframe clouds
     std::vector<unsigned char> saveMap() {
         size_t need = 0;
-        check(ndt_map_save(handle(), nullptr, 0, &need));
+        check(ndt_map_save(handle_or_throw(), nullptr, 0, &need));
         std::vector<unsigned char> blob(need);
-        check(ndt_map_save(handle(), blob.data(), blob.size(), &need));
+        check(ndt_map_save(handle_or_throw(), blob.data(), blob.size(), &need));
         return blob;
     }
-    void loadMap(const std::vector<unsigned char>& blob) { check(ndt_map_load(handle(), blob.data(), blob.size())); }
+    void loadMap(const std::vector<unsigned char>& blob) {
+        if (ndt_handle* h = handle("loadMap")) note("loadMap", ndt_map_load(h, blob.data(), blob.size()));
+    }
     // Offline replay (ndt_align_batch; no counterpart in the reference, which aligns one frame at a time): many
     // (scan, initial pose) pairs against the resident target in one batched Gauss-Newton loop.  pair_scan[p] is the
     // scan of pair p (empty: pair p uses scan p); guesses are column-major 4x4.  results[p].status tells how pair p ended.
@@ -142,24 +197,40 @@ class NormalDistributionsTransform {
         std::vector<double> g(16 * guesses.size());
         for (size_t p = 0; p < guesses.size(); ++p) for (int i = 0; i < 16; ++i) g[16 * p + i] = guesses[p][i];
         std::vector<ndt_result> out(guesses.size());
-        check(ndt_align_batch(handle(), pts.data(), sizeof(PointSource), off.data(), scans.size(), pair_scan.empty() ? nullptr : pair_scan.data(),
+        check(ndt_align_batch(handle_or_throw(), pts.data(), sizeof(PointSource), off.data(), scans.size(), pair_scan.empty() ? nullptr : pair_scan.data(),
                               guesses.size(), g.data(), out.data()));
         return out;
     }
     const ndt_result& result() const { return res_; }
     int status() const { return status_; }
-    std::string lastError() const { return h_ ? ndt_last_error(h_) : "no handle"; }
+    std::string lastError() const { return err_; }
 
   private:
-    ndt_handle* handle() {
+    // the engine is created on first use (the reference constructs its member before any parameter is known)
+    ndt_handle* handle(const char* where) {
         if (!h_) {
             h_ = ndt_create(&cfg_);
-            if (!h_) throw Error(NDT_ERR_HIP, "ndt_create failed: no MI355X visible or bad configuration");
+            if (!h_) { fail(where, NDT_ERR_HIP, "ndt_create failed: no MI355X visible or bad configuration"); return nullptr; }
         }
         return h_;
     }
-    void reconfigure() { if (h_) check(ndt_configure(h_, &cfg_)); }
-    void check(int rc) { if (rc != NDT_OK) throw Error(rc, ndt_last_error(h_)); }
+    ndt_handle* handle_or_throw() {
+        if (!handle("ndt_mi355")) throw Error(status_, err_);
+        return h_;
+    }
+    void reconfigure() { if (h_) note("set*", ndt_configure(h_, &cfg_)); }
+    void note(const char* where, int rc) {
+        status_ = rc;
+        if (rc != NDT_OK) fail(where, rc, ndt_last_error(h_));
+    }
+    void fail(const char* where, int rc, const std::string& msg) {
+        status_ = rc;
+        err_ = std::string(where) + ": " + msg;
+        res_.converged = 0;
+        std::fprintf(stderr, "[ndt_mi355] %s (status %d)\n", err_.c_str(), rc);   // PCL_ERROR's role
+        if (throw_) throw Error(rc, err_);
+    }
+    void check(int rc) { if (rc != NDT_OK) { status_ = rc; err_ = ndt_last_error(h_); throw Error(rc, err_); } }
 
     ndt_config cfg_{};
     ndt_pcl_params pcl_{};
@@ -168,6 +239,8 @@ class NormalDistributionsTransform {
     ndt_handle* h_ = nullptr;
     ndt_result res_{};
     int status_ = NDT_OK;
+    std::string err_;
+    bool throw_ = false;
 };
 
 }  // namespace ndt_mi355

@@ -50,6 +50,7 @@ enum { NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
 
 struct ndt_handle {
     ndt_config cfg;
+    int n_cu = 256;              // compute units of cfg.device: every grid of this handle is sized from it
     hipStream_t stream = nullptr;
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};   // further launch lanes of a replay batch (independent pairs: no ordering between lanes)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -63,7 +64,7 @@ struct ndt_handle {
     bool have_source = false;
     DevBuf partials, partials2, cell_keys, cell_mask, pcl_partials;
     GnState* d_state = nullptr;
-    GnState* d_state2 = nullptr;               // the chained loop ping-pongs between the two; d_state always names the current one
+    GnState* d_state2 = nullptr;               // the chained loop ping-pongs between the two (GnBuffers below)
     bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
     std::string err;
@@ -108,6 +109,11 @@ static int check_cfg(const ndt_config* c, std::string& err) {
     return NDT_OK;
 }
 
+// where one Gauss-Newton loop keeps its device-side working state: rows[2] are partial-row buffers (>= grid rows each),
+// st[2] the two states the chained loop ping-pongs between
+struct GnBuffers { double* rows[2]; GnState* st[2]; };
+struct SourceView { const float *x, *y, *z; size_t n; };
+
 extern "C" {
 
 void ndt_default_config(ndt_config* c) {
@@ -126,10 +132,11 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return nullptr;
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
     int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess) residual_set_cu_count(n_cu);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) n_cu = 256;
     ndt_handle* h = new (std::nothrow) ndt_handle();
     if (!h) return nullptr;
     h->cfg = *cfg;
+    h->n_cu = n_cu;
     h->use_links = getenv("NDT_NO_LINKS") ? 0 : 1;
     h->use_chain = getenv("NDT_NO_CHAIN") == nullptr;
     if (const char* e = getenv("NDT_BATCH_LANES")) h->batch_lanes = std::min(4, std::max(1, atoi(e)));
@@ -217,8 +224,8 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
         H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
         H_TRY(unpack_points_soa(h->sraw.p, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
     }
-    H_TRY(h->partials.ensure((size_t)residual_grid(n) * ACC_N * sizeof(double)));
-    H_TRY(h->partials2.ensure((size_t)residual_grid(n) * ACC_N * sizeof(double)));
+    H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
+    H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
     H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
     h->n_src = n;
     h->have_source = true;
@@ -244,8 +251,8 @@ int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t 
     if (d_n_out) H_TRY(hipMemcpyAsync(&n32, d_n_out, 4, hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));        // the only wait after the bounding box: the caller's buffer is free, n is known
     const size_t n_out = n32;
-    H_TRY(h->partials.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
-    H_TRY(h->partials2.ensure((size_t)residual_grid(n_out) * ACC_N * sizeof(double)));
+    H_TRY(h->partials.ensure((size_t)residual_grid(n_out, h->n_cu) * ACC_N * sizeof(double)));
+    H_TRY(h->partials2.ensure((size_t)residual_grid(n_out, h->n_cu) * ACC_N * sizeof(double)));
     h->n_src = n_out;
     h->have_source = true;
     return NDT_OK;
@@ -332,15 +339,18 @@ static hipEvent_t next_event(ndt_handle* h) {
     }
     return h->ev_pool[h->ev_used++];
 }
-// queues one residual pass (+ fixed-order reduction, + all-reduce across ranks, + optional GN step)
-static int queue_pass(ndt_handle* h, int do_solve, int force, int64_t* keys_out, uint8_t* mask_out) {
-    const int grid = residual_grid(h->n_src);
+static SourceView resident_source(const ndt_handle* h) { return SourceView{h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->n_src}; }
+static GnBuffers handle_buffers(const ndt_handle* h) { return GnBuffers{{h->partials.as<double>(), h->partials2.as<double>()}, {h->d_state, h->d_state2}}; }
+// queues one residual pass over `src` at the pose in `st` (+ fixed-order reduction of the rows, + all-reduce across
+// ranks, + optional GN step)
+static int queue_pass(ndt_handle* h, const SourceView& src, int grid, double* rows, GnState* st, int do_solve, int force, int64_t* keys_out,
+                      uint8_t* mask_out) {
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) { e0 = next_event(h); e1 = next_event(h); if (e0) (void)hipEventRecord(e0, h->stream); }
-    launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
-                    h->d_state, ep, h->partials.as<double>(), grid, force, keys_out, mask_out, h->use_links, h->stream);
+    launch_residual(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), st, ep, rows, grid, force, keys_out,
+                    mask_out, h->use_links, h->stream);
     if (h->prof && e1) (void)hipEventRecord(e1, h->stream);
     if (h->comm) {
         // local fixed-order sum into the send row, all-reduce into the receive row, then the same step on
@@ -348,12 +358,12 @@ static int queue_pass(ndt_handle* h, int do_solve, int force, int64_t* keys_out,
         // ranks never diverge in the number of collectives they queue.
         double* send = h->comm_rows.as<double>();
         double* recv = send + ACC_N;
-        launch_reduce_rows(h->partials.as<double>(), grid, h->d_state, send, force, h->stream);
+        launch_reduce_rows(rows, grid, st, send, force, h->stream);
         int rc = g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream);
         if (rc != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
-        launch_solve_only(h->d_state, recv, sp, do_solve, force, h->stream);
+        launch_solve_only(st, recv, sp, do_solve, force, h->stream);
     } else {
-        launch_reduce_solve(h->partials.as<double>(), grid, h->d_state, sp, do_solve, force, h->stream);
+        launch_reduce_solve(rows, grid, st, sp, do_solve, force, h->stream);
     }
     H_TRY(hipGetLastError());
     return NDT_OK;
@@ -373,7 +383,7 @@ int ndt_eval(ndt_handle* h, const double T[16], double H[36], double b[6], doubl
     H_TRY(hipSetDevice(h->cfg.device));
     state_from_T(h->h_state, T);
     H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
-    if ((rc = queue_pass(h, 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
+    if ((rc = queue_pass(h, resident_source(h), residual_grid(h->n_src, h->n_cu), h->partials.as<double>(), h->d_state, 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
     H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipStreamSynchronize(h->stream));
     if (h->prof) { collect_profile(h); h->prof_hits += h->h_state->acc[ACC_HITS]; h->prof_pts += (double)h->n_src; }
@@ -394,7 +404,8 @@ int ndt_source_cells(ndt_handle* h, const double T[16], int64_t* keys, uint8_t* 
     state_from_T(h->h_state, T);
     H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
     void* saved = h->comm; h->comm = nullptr;   // a local diagnostic: no collective
-    rc = queue_pass(h, 0, 1, h->cell_keys.as<int64_t>(), h->cell_mask.as<uint8_t>());
+    rc = queue_pass(h, resident_source(h), residual_grid(h->n_src, h->n_cu), h->partials.as<double>(), h->d_state, 0, 1, h->cell_keys.as<int64_t>(),
+                    h->cell_mask.as<uint8_t>());
     h->comm = saved;
     if (rc != NDT_OK) return rc;
     H_TRY(hipMemcpyAsync(keys, h->cell_keys.p, h->n_src * 8, hipMemcpyDeviceToHost, h->stream));
@@ -404,11 +415,8 @@ int ndt_source_cells(ndt_handle* h, const double T[16], int64_t* keys, uint8_t* 
     return NDT_OK;
 }
 
-int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
-    int rc = ready(h);
-    if (rc != NDT_OK) return rc;
-    if (!guess || !out) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
-    H_TRY(hipSetDevice(h->cfg.device));
+// The Gauss-Newton loop of ndt_align over `src`, with its device-side working state in `B` (the handle's buffers) and `grid` rows per launch.
+static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffers& B, const double guess[16], ndt_result* out) {
     memset(out, 0, sizeof *out);
     state_from_T(h->h_state, guess);
     const int max_it = h->cfg.max_iterations;
@@ -417,60 +425,60 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     // (profiling times the residual launches alone; every block re-reads all rows of the previous launch and repeats the
     // solve, which only pays while no CU runs more than one block per launch: measured, 230 blocks 0.134 -> 0.123 ms per
     // align, 489 blocks 0.191 -> 0.221 ms)
-    const bool chain_fits = h->use_chain && !h->prof && h->n_src > 0 && residual_grid(h->n_src) <= residual_cu_count();
+    const bool chain_fits = h->use_chain && !h->prof && src.n > 0 && grid <= h->n_cu;
     const bool chained = chain_fits && !h->comm;
     const bool chained_comm = chain_fits && h->comm;
+    int cur = 0;                        // B.st[cur] is the current state; the chained launches ping-pong
+    int rcur = 0;                       // B.rows[rcur] is where the next launch writes its rows
     // the chained loop's first launch takes the initial pose as a kernel argument; the other forms read it from HBM
-    if (!chained) H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
+    if (!chained) H_TRY(hipMemcpyAsync(B.st[cur], h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
     GnState init_state = *h->h_state;
     bool first_launch = true;
     const EvalParams ep = eval_params(h);
     const SolveParams sp = solve_params(h);
+    int rc;
     int queued = 0;
     while (queued < max_it) {
         const int m = std::min(chunk, max_it - queued);
         if (chained) {
             // m iterations = m chained launches (launch i carries the step of launch i - 1) + the last step on its own
-            const int grid = residual_grid(h->n_src);
             for (int i = 0; i < m; ++i) {
-                launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
-                                      (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, h->partials2.as<double>(), i ? grid : 0, sp, ep,
-                                      h->partials.as<double>(), grid, h->use_links, first_launch ? &init_state : nullptr, h->stream);
+                launch_residual_chain(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), B.st[cur], B.st[cur ^ 1],
+                                      B.rows[rcur ^ 1], i ? grid : 0, sp, ep, B.rows[rcur], grid, h->use_links, first_launch ? &init_state : nullptr,
+                                      h->stream);
                 first_launch = false;
-                std::swap(h->d_state, h->d_state2);               // the launch published the state it used in st_out
-                std::swap(h->partials, h->partials2);             // partials2 = the rows just written
+                cur ^= 1;               // the launch published the state it used in the other buffer
+                rcur ^= 1;              // rows[rcur ^ 1] = the rows just written
             }
-            launch_reduce_solve(h->partials2.as<double>(), grid, h->d_state, sp, 1, 0, h->stream);
+            launch_reduce_solve(B.rows[rcur ^ 1], grid, B.st[cur], sp, 1, 0, h->stream);
             H_TRY(hipGetLastError());
         } else if (chained_comm) {
             // sharded source: launch i takes the step from the all-reduced row of launch i - 1 in its prologue (one "row" to sum),
             // then residual -> local fixed-order sum -> all-reduce; three launches per iteration instead of four
-            const int grid = residual_grid(h->n_src);
             double* send = h->comm_rows.as<double>();
             double* recv = send + ACC_N;
             for (int i = 0; i < m; ++i) {
-                launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,
-                                      (uint32_t)(h->map.cap - 1), h->d_state, h->d_state2, recv, i ? 1 : 0, sp, ep, h->partials.as<double>(), grid,
-                                      h->use_links, nullptr, h->stream);
-                std::swap(h->d_state, h->d_state2);
-                launch_reduce_rows(h->partials.as<double>(), grid, h->d_state, send, 0, h->stream);
+                launch_residual_chain(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), B.st[cur], B.st[cur ^ 1], recv,
+                                      i ? 1 : 0, sp, ep, B.rows[0], grid, h->use_links, nullptr, h->stream);
+                cur ^= 1;
+                launch_reduce_rows(B.rows[0], grid, B.st[cur], send, 0, h->stream);
                 if (g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream) != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
             }
-            launch_solve_only(h->d_state, recv, sp, 1, 0, h->stream);
+            launch_solve_only(B.st[cur], recv, sp, 1, 0, h->stream);
             H_TRY(hipGetLastError());
         } else {
             for (int i = 0; i < m; ++i)
-                if ((rc = queue_pass(h, 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
+                if ((rc = queue_pass(h, src, grid, B.rows[0], B.st[cur], 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
         }
         queued += m;
-        H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
         if (h->h_state->done) break;
     }
     const GnState loop = *h->h_state;
     if (loop.status == NDT_OK && h->cfg.final_eval) {   // H, b, chi2 at the pose that is returned
-        if ((rc = queue_pass(h, 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
-        H_TRY(hipMemcpyAsync(h->h_state, h->d_state, sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        if ((rc = queue_pass(h, src, grid, B.rows[0], B.st[cur], 0, 1, nullptr, nullptr)) != NDT_OK) return rc;
+        H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
     }
     if (h->prof) collect_profile(h);
@@ -483,12 +491,20 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     out->iterations = loop.iter;
     out->converged = loop.converged;
     out->status = loop.status;
-    if (h->prof) { h->prof_hits += st->acc[ACC_HITS]; h->prof_pts += (double)h->n_src; }
+    if (h->prof) { h->prof_hits += st->acc[ACC_HITS]; h->prof_pts += (double)src.n; }
     if (loop.status != NDT_OK) {
         h->err = loop.status == NDT_ERR_TOO_FEW_POINTS ? "fewer accepted residuals than min_effective_pts" : "Hessian not positive definite";
         return loop.status;
     }
     return NDT_OK;
+}
+
+int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!guess || !out) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    return gn_loop(h, resident_source(h), residual_grid(h->n_src, h->n_cu), handle_buffers(h), guess, out);
 }
 
 int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean, double* cov, double* info, uint8_t* valid,
@@ -610,7 +626,7 @@ static int pcl_engine(ndt_handle* h, const ndt_pcl_params* prm, PclEngine* e) {
         return NDT_ERR_INVALID_ARG;
     }
     H_TRY(hipSetDevice(h->cfg.device));
-    H_TRY(h->pcl_partials.ensure(((size_t)pcl_grid(h->n_src) + 1) * ACC_N * sizeof(double)));
+    H_TRY(h->pcl_partials.ensure(((size_t)pcl_grid(h->n_src, h->n_cu) + 1) * ACC_N * sizeof(double)));
     e->stream = h->stream;
     e->keys = h->map.keys; e->slots = h->map.slots; e->mask = (uint32_t)(h->map.cap - 1);
     e->sx = h->sx.as<float>(); e->sy = h->sy.as<float>(); e->sz = h->sz.as<float>(); e->n = h->n_src;
@@ -618,6 +634,7 @@ static int pcl_engine(ndt_handle* h, const ndt_pcl_params* prm, PclEngine* e) {
     e->partials = h->pcl_partials.as<double>() + ACC_N;
     e->d_row = h->pcl_partials.as<double>();
     e->use_links = h->use_links;
+    e->n_cu = h->n_cu;
     e->h_row = h->h_state->acc;          // pinned; the Gauss-Newton loop is not running while this mode is
     return NDT_OK;
 }
@@ -764,7 +781,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
         lanes[l].p0 = l * per; lanes[l].np = std::min(per, n_pairs - l * per);
     }
     const size_t group = std::min(CH, lanes[0].np);      // the largest launch: sizes the grid rows for all of them
-    const int rows = residual_grid((size_t)max_pts, group, h->cfg.nearby);
+    const int rows = residual_grid((size_t)max_pts, h->n_cu, group, h->cfg.nearby);
     H_TRY(h->bpartials.ensure(n_pairs * (size_t)rows * ACC_N * sizeof(double)));
     H_TRY(h->bdone.ensure(256));
     H_TRY(hipMemsetAsync(h->bdone.p, 0, 256, s));
@@ -888,7 +905,7 @@ int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_pe
     H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
     state_from_T(h->h_state, T);
     H_TRY(hipMemcpyAsync(h->d_state, h->h_state, sizeof(GnState), hipMemcpyHostToDevice, h->stream));
-    const int grid = residual_grid(h->n_src);
+    const int grid = residual_grid(h->n_src, h->n_cu);
     const EvalParams ep = eval_params(h);
     auto pass = [&]() {
         launch_residual(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots,

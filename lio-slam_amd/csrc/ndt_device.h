@@ -98,8 +98,9 @@ __host__ __device__ inline uint32_t ndt_hash_key(int64_t k) {
 }
 __device__ inline bool ndt_in_range(double v) { return v >= -(double)NDT_KEY_BIAS && v < (double)NDT_KEY_BIAS; }
 
-// Arithmetic contract with the oracle: plain float64 multiplies and adds in this order,
-// no contraction (the library is built with -ffp-contract=off).
+// Arithmetic contract with the oracle: plain float64 multiplies and adds in this order, nothing fused by
+// the compiler (the library is built with -ffp-contract=off); the explicit fma() calls in the residual kernels' gate are
+// part of the contract and written the same way in the oracle.
 __device__ inline void ndt_xform(const double* R, const double* t, float xf, float yf, float zf, double q[3]) {
     double x = xf, y = yf, z = zf;
 #pragma unroll

@@ -97,8 +97,9 @@ struct PclEngine {            // what a pass needs from the handle
     double* d_row;            // ACC_N doubles, device
     double* h_row;            // ACC_N doubles, pinned host
     int use_links;            // 9 hashed cells + x-links instead of 27 hashed cells
+    int n_cu;                 // compute units of the handle's device
 };
-int pcl_grid(size_t n);
+int pcl_grid(size_t n, int n_cu);
 void pcl_matrix_from_vector(const double p[6], double T[16]);
 void pcl_vector_from_matrix(const double T[16], double p[6]);
 int pcl_eval(const PclEngine& e, const ndt_pcl_params& prm, const double p[6], double* score, double g[6], double* H, int64_t* n_nb, std::string& err);
@@ -109,9 +110,8 @@ int pcl_align(const PclEngine& e, const ndt_pcl_params& prm, int max_iterations,
 hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* x, float* y, float* z, hipStream_t s);
 
 // ---- ndt_residual.hip
-int residual_grid(size_t n, size_t problems = 1, int nearby = 7);
-int residual_cu_count();
-void residual_set_cu_count(int n);        // compute units of the device (256 on MI355X): sizes the batched grids
+// n_cu: compute units of the handle's device (256 on MI355X; read at ndt_create and kept in the handle): sizes every grid
+int residual_grid(size_t n, int n_cu, size_t problems = 1, int nearby = 7);
 // chained single-scan iteration: previous launch's reduction + step in every block's prologue, then the residual pass
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,

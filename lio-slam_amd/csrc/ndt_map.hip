@@ -163,11 +163,11 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
 // pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
 // km.mn/bits are listed most-significant axis first; km.axis[] says which cell coordinate each one is
 // (x,y,z for the map build; z,y,x for PCL VoxelGrid's output order).
-__global__ void k_sort_keys(int64_t* keys, size_t n, SortKeyMap km) {
+__global__ void k_sort_keys(int64_t* keys, size_t n, SortKeyMap km, uint64_t invalid_sk) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t k = keys[i];
-    uint64_t sk = ~0ull;
+    uint64_t sk = invalid_sk;      // one bit above every valid key: sorts behind the max-corner cell even when all its bits are ones
     if (k != NDT_KEY_EMPTY) {
         int32_t c[3];
         ndt_unpack(k, c[0], c[1], c[2]);
@@ -825,11 +825,15 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
         km.bits[j] = bits_for((int64_t)misc[3 + ax] - misc[ax] + 1);
         total_bits += km.bits[j];
     }
-    k_sort_keys<<<nb256, 256, 0, s>>>(w.keys_a.as<int64_t>(), n, km);
+    // Points that were dropped (non-finite / out of key range) get a sort key of their own, 1 << total_bits, so that they
+    // can never tie with the all-ones key of the bounding box's max corner (a 128 x 128 x 4 box has exactly 16 key bits);
+    // the extra bit is sorted only when such points exist.
+    const bool has_invalid = n_valid < n;
+    k_sort_keys<<<nb256, 256, 0, s>>>(w.keys_a.as<int64_t>(), n, km, 1ull << total_bits);
     HIP_TRY(hipGetLastError());
 
     // LSD radix sort over the bits that exist
-    const int P = std::max(1, (total_bits + 7) / 8);
+    const int P = std::max(1, (total_bits + (has_invalid ? 1 : 0) + 7) / 8);
     const bool big = n >= (1u << 20);
     const size_t rs_tile = (size_t)RS_THREADS * (big ? RS_ITEMS_BIG : RS_ITEMS_SMALL);
     const unsigned nblk = (unsigned)((n + rs_tile - 1) / rs_tile);

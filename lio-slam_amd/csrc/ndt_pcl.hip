@@ -445,7 +445,7 @@ struct Driver {
         std::memcpy(pp.aj, aj, sizeof aj); std::memcpy(pp.ah, ah, sizeof ah);
         pp.d1 = d1; pp.d2 = d2; pp.kp = e->kp;
         pp.r2f = (float)(e->kp.res_d * e->kp.res_d);
-        const int grid = pcl_grid(e->n);
+        const int grid = pcl_grid(e->n, e->n_cu);
         launch_pass(*e, pp, grid, with_gradient, with_hessian);
         k_pcl_reduce<<<1, 1024, 0, e->stream>>>(e->partials, grid, e->d_row);
         hipError_t rc = hipGetLastError();
@@ -476,10 +476,10 @@ struct Driver {
 
 }  // namespace
 
-int pcl_grid(size_t n) {
+int pcl_grid(size_t n, int n_cu) {
     // one point per lane up to one round of resident blocks (two 256-thread blocks per CU at 256 VGPRs), then the lanes loop
     size_t g = (n + PCL_THREADS - 1) / PCL_THREADS;
-    const size_t cap = (size_t)2 * (size_t)residual_cu_count();
+    const size_t cap = (size_t)2 * (size_t)(n_cu > 0 ? n_cu : 256);
     return (int)(g < 1 ? 1 : g > cap ? cap : g);
 }
 
@@ -641,7 +641,7 @@ int pcl_time_pass(const PclEngine& e, const ndt_pcl_params& prm, const double p[
     hipError_t hr = hipEventCreate(&a);
     if (hr == hipSuccess) hr = hipEventCreate(&b);
     if (hr != hipSuccess) { err = hipGetErrorString(hr); return NDT_ERR_HIP; }
-    const int grid = pcl_grid(e.n);
+    const int grid = pcl_grid(e.n, e.n_cu);
     (void)hipEventRecord(a, e.stream);
     for (int i = 0; i < reps; ++i) {
         launch_pass(e, pp, grid, true, with_hessian);

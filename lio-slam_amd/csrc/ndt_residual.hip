@@ -16,7 +16,6 @@
 // Bound: HBM/L2 gather (12 + 8K + 40h algorithmic bytes per point); no MFMA.
 #include "ndt_internal.h"
 
-#include <atomic>
 #include <cstddef>
 #include "ndt_kernels.h"
 
@@ -397,16 +396,14 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual_batch(const float* __r
 // Blocks for a launch over n points of one problem, `problems` of them side by side.  One point per lane while
 // the whole launch is small (latency-bound: every wave should be resident at once); more points per lane once the
 // launch would not fit the GPU in one go, which amortises the per-block reduction tail and shrinks the row count.
-static std::atomic<int> g_cu_count{256};     // set from ndt_create, possibly on several host threads
-void residual_set_cu_count(int n) { if (n > 0) g_cu_count.store(n, std::memory_order_relaxed); }
-int residual_cu_count() { return g_cu_count.load(std::memory_order_relaxed); }
-int residual_grid(size_t n, size_t problems, int nearby) {
+int residual_grid(size_t n, int n_cu, size_t problems, int nearby) {
+    if (n_cu <= 0) n_cu = 256;
     if (problems <= 1) {                              // k_residual: 512-thread blocks
         // one point per lane while that fits one round of resident blocks (one 512-thread block per CU at 256 VGPRs); beyond
         // that the lanes loop, the launch stays one round and its rows stay few enough for the chained loop (2 M points:
         // 0.72 -> 0.53 ms per 10-iteration align against a 2048-block grid)
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
-        const size_t cap = (size_t)g_cu_count.load(std::memory_order_relaxed);
+        const size_t cap = (size_t)n_cu;
         return (int)(g < 1 ? 1 : g > cap ? cap : g);
     }
     // Batched launches: 256-thread blocks, two resident per CU (241 VGPRs), each lane works through `ppt` points.  The
@@ -415,7 +412,7 @@ int residual_grid(size_t n, size_t problems, int nearby) {
     // blocks — 8 pairs of 118 k points run as 464 blocks of 8 points per lane rather than 528 blocks of 7 (two rounds),
     // 32 pairs as 512 blocks of 29, 128 pairs as 512 blocks of 115 (measured sweeps: DESIGN.md §5).
     // (NEARBY1 needs 138 VGPRs and is bandwidth-bound: measured best with four blocks per CU in flight)
-    const size_t resident = (size_t)(nearby == 1 ? 4 : 2) * (size_t)g_cu_count.load(std::memory_order_relaxed);
+    const size_t resident = (size_t)(nearby == 1 ? 4 : 2) * (size_t)n_cu;
     size_t best_ppt = 1, best_cost = ~(size_t)0;
     for (size_t ppt = 128; ppt >= 1; --ppt) {
         const size_t rows = (n + RES_THREADS * ppt - 1) / (RES_THREADS * ppt);

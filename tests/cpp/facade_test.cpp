@@ -20,6 +20,20 @@ struct alignas(16) Point {   // slam_czc::Point (src/slam/include/utility.h:54-6
 static_assert(sizeof(Point) == 32, "layout of slam_czc::Point");
 using PointCloud = std::vector<Point>;
 
+// Stand-in for Eigen::Matrix4f (Eigen is not in the image): 16 column-major floats behind data(), default-constructible,
+// copyable — what the facade needs of `Eigen::Matrix4f ndt_pose_` (src/slam/include/process.h:87).
+struct Matrix4f {
+    float m[16];
+    float* data() { return m; }
+    const float* data() const { return m; }
+    float& operator()(int r, int c) { return m[c * 4 + r]; }
+};
+// Stand-in for State::getTransform() (src/slam/src/utility.cc:22-35): returns the Matrix4f by value
+struct State {
+    Matrix4f T;
+    Matrix4f getTransform() const { return T; }
+};
+
 static std::shared_ptr<PointCloud> read_cloud(FILE* f) {
     std::uint64_t n = 0;
     if (fread(&n, 8, 1, f) != 1) exit(3);
@@ -50,9 +64,17 @@ int main(int argc, char** argv) {
     ndt_.setInputTarget(pc_key);         // process.cc:78
     ndt_.addTargetCloud(*keyframe, Tk);  // process.cc:134-147, incrementally
     ndt_.setInputSource(scan);           // process.cc:87
-    PointCloud output;
-    ndt_.align(output, guess);           // process.cc:94   (Matrix4f guess)
-    auto T = ndt_.getFinalTransformation();   // process.cc:95
+    // process.cc:92-95 exactly as the reference has them (PointType::Ptr output; Eigen::Matrix4f ndt_pose_)
+    State current_state_;
+    for (int i = 0; i < 16; ++i) current_state_.T.m[i] = guess[i];
+    Matrix4f ndt_pose_;
+    std::shared_ptr<PointCloud> output(new PointCloud);
+    ndt_pose_ = current_state_.getTransform();
+    ndt_.align(*output, ndt_pose_);
+    ndt_pose_ = ndt_.getFinalTransformation();
+    std::array<double, 16> T = ndt_.getFinalTransformation();
+    double m4f_diff = 0.0;                                // the Matrix4f is the float32 rounding of the double pose
+    for (int i = 0; i < 16; ++i) m4f_diff = std::max(m4f_diff, std::fabs((double)ndt_pose_.m[i] - (double)(float)T[i]));
     auto H = ndt_.getHessian();
     printf("status %d converged %d iterations %d\n", ndt_.status(), (int)ndt_.hasConverged(), ndt_.getFinalNumIteration());
     for (double v : T) printf("%.17g ", v);
@@ -73,11 +95,23 @@ int main(int argc, char** argv) {
     }
     // the same call sequence in PCL compatibility mode (what the reference's PCL build computes at process.cc:94)
     ndt_.setPclCompatibility(true);
-    ndt_.align(output, guess);
-    auto Tp = ndt_.getFinalTransformation();
+    ndt_.align(*output, guess);          // a raw column-major float[16] works too
+    std::array<double, 16> Tp = ndt_.getFinalTransformation();
     printf("status %d converged %d iterations %d probability %.17g\n", ndt_.status(), (int)ndt_.hasConverged(), ndt_.getFinalNumIteration(),
            ndt_.getTransformationProbability());
     for (double v : Tp) printf("%.17g ", v);
     printf("\n");
+    printf("matrix4f %.3g\n", m4f_diff);
+    // PCL-like error behaviour: a failing call does not throw; it is recorded and clears hasConverged()
+    ndt_.setPclCompatibility(false);
+    PointCloud empty;
+    ndt_mi355::NormalDistributionsTransform<Point, Point> fresh;
+    fresh.setResolution(-1.0f);          // invalid: recorded at first use
+    fresh.setInputSource(scan);
+    const int st_bad = fresh.status();
+    ndt_mi355::NormalDistributionsTransform<Point, Point> no_target;
+    no_target.setInputSource(scan);
+    no_target.align(*output, ndt_pose_);
+    printf("errors %d %d %d\n", st_bad, no_target.status(), (int)no_target.hasConverged());
     return 0;
 }

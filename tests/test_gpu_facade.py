@@ -50,3 +50,9 @@ def test_cpp_facade_matches_oracle(tmp_path):
     assert abs(float(st2[7]) - rp["trans_probability"]) <= 1e-6 * abs(rp["trans_probability"])
     dt, dr = pose_error(Tp, rp["T"])
     assert dt < 1e-6 and dr < 1e-7
+    # process.cc:94-95 written as the reference has them, through a 16-float column-major matrix type passed by value
+    m4 = lines[6].split()
+    assert m4[0] == "matrix4f" and float(m4[1]) == 0.0
+    # PCL-like error behaviour: no exception, status recorded (bad config -> create fails: HIP; align without a target: NO_TARGET)
+    er = lines[7].split()
+    assert er[0] == "errors" and int(er[1]) == -4 and int(er[2]) == -2 and int(er[3]) == 0

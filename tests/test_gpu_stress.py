@@ -172,3 +172,31 @@ def test_chained_loop_matches_two_launch_loop_bit_for_bit(monkeypatch):
             assert np.array_equal(a[k], b[k], equal_nan=True), k
         assert a["chi2"] == b["chi2"] and a["n_effective"] == b["n_effective"] and a["last_dx_norm"] == b["last_dx_norm"]
     assert res[0][0]["iterations"] < 35 and res[0][5]["iterations"] == 7
+
+
+def test_dropped_points_never_tie_with_the_max_corner_cell():
+    """A bounding box of exactly 128 x 128 x 4 cells has 16 sort-key bits and the (max, max, max) cell's key is all ones:
+    dropped points (NaN, inf, out of key range) must still sort behind it, in the map build and in the VoxelGrid path."""
+    import lio_slam_amd as la
+    from oracle.oracle import Oracle, voxel_downsample
+    rng = np.random.default_rng(128)
+    cells = np.array([[0, 0, 0], [127, 127, 3], [127, 127, 2], [126, 127, 3], [5, 9, 1], [64, 64, 2]])
+    pts = (cells[:, None, :] + rng.uniform(0.05, 0.95, (len(cells), 9, 3))).reshape(-1, 3).astype(np.float32)
+    bad = np.full((40, 3), np.nan, np.float32); bad[::3, 1] = np.inf; bad[1::3] = [3e6, 1.0, 1.0]
+    cloud = np.concatenate([pts, bad])
+    cloud = cloud[rng.permutation(len(cloud))]
+    n = la.NDT(); o = Oracle()
+    n.set_target(cloud); o.set_target(cloud)
+    vg, vo = n.export_voxels(), o.export_voxels()
+    assert len(vg["keys"]) == len(cells)
+    assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"]) and np.all(vg["counts"] == 9)
+    assert np.array_equal(vg["valid"], vo["valid"]) and np.isfinite(vg["mean"]).all() and np.isfinite(vg["cov"]).all()
+    np.testing.assert_allclose(vg["mean"], vo["mean"], rtol=0, atol=1e-9)
+    n.add_target(cloud); o.add_target(cloud)                           # the merge path sorts the same way
+    vg, vo = n.export_voxels(), o.export_voxels()
+    assert np.array_equal(vg["keys"], vo["keys"]) and np.all(vg["counts"] == 18) and np.array_equal(vg["counts"], vo["counts"])
+    # VoxelGrid with leaf 1.0 on the same cloud: six centroids in PCL's index order, none of them NaN
+    n.set_source_downsampled(cloud, leaf=1.0)
+    got = n.get_source(); want = voxel_downsample(cloud, 1.0)
+    assert got.shape == want.shape == (len(cells), 3) and np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
