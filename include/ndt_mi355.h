@@ -133,6 +133,22 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]);
  * as the reference never checks convergence. */
 int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out);
 
+/* ndt_align for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (which has no device memory at all): it is
+ * for callers that may not call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  The source cloud is handed over as three float32 arrays the caller holds in device memory (x[n], y[n],
+ * z[n]; non-finite points are skipped), the map is the handle's resident one, the result goes to *out as in ndt_align.
+ * The loop's scratch — two buffers of per-block partial rows and two Gauss-Newton states, 132 096 bytes — lives in a
+ * file-scope `static __device__` array of the library instead of allocated buffers (every GPU the library runs on holds
+ * its own copy until the process ends), so this call makes no hipMalloc / hipFree / allocating library call.
+ *   - n may be at most NDT_STATIC_MAX_POINTS; more is rejected with NDT_ERR_CAPACITY (use ndt_set_source + ndt_align);
+ *   - not available on a handle with a communicator (ndt_comm_init) or with profiling enabled: NDT_ERR_INVALID_ARG;
+ *   - all calls on one GPU share that GPU's array (also across handles): calls that overlap on one GPU race; serialise
+ *     them.  ndt_align and every other entry point keep using the handle's own buffers and are not affected;
+ *   - on MI355X the launch geometry equals ndt_align's for the same n, so both return the same bits. */
+#define NDT_STATIC_MAX_POINTS (1u << 22)
+int ndt_align_static(ndt_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, const double guess[16],
+                     ndt_result* out);
+
 /* One residual/accumulation pass at pose T: the unit of work inside align's
  * loop; no reference counterpart is callable on its
  * own.  Any output pointer may be NULL. */

@@ -23,7 +23,7 @@ ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP
 
 ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
-    "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
+    "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_align_static", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
     "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version", "ndt_last_radix_passes",
@@ -98,6 +98,7 @@ def lib():
     L.ndt_get_source.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.ndt_add_target_from_source.argtypes = [vp, vp]
     L.ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
+    L.ndt_align_static.argtypes = [vp, vp, vp, vp, sz, vp, C.POINTER(Result)]
     L.ndt_eval.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ndt_source_cells.argtypes = [vp, vp, vp, vp, sz]
     L.ndt_source_size.restype = C.c_int64
@@ -356,6 +357,17 @@ class NDT:
                           chi2=r.chi2, n_effective=r.n_effective, iterations=r.iterations, converged=bool(r.converged),
                           last_dx_norm=r.last_dx_norm)
         return self.final
+
+    def align_static(self, d_x, d_y, d_z, n, guess, check=True):
+        """ndt_align_static: the entry point that allocates nothing.  d_x / d_y / d_z are device addresses (ints) of the
+        caller's float32 arrays of n source coordinates each; same result dict as align()."""
+        t = _T(guess)
+        r = Result()
+        rc = lib().ndt_align_static(self._h, int(d_x), int(d_y), int(d_z), int(n), t.ctypes.data, C.byref(r))
+        if check:
+            self._chk(rc)
+        return dict(rc=rc, T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6), b=np.array(r.b), chi2=r.chi2,
+                    n_effective=r.n_effective, iterations=r.iterations, converged=bool(r.converged), last_dx_norm=r.last_dx_norm)
 
     def align_batch(self, scans, guesses, pair_scan=None):
         """Offline replay: align many (scan, guess) pairs against the resident map in one batched Gauss-Newton loop.

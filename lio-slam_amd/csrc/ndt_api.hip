@@ -65,6 +65,7 @@ struct ndt_handle {
     DevBuf partials, partials2, cell_keys, cell_mask, pcl_partials;
     GnState* d_state = nullptr;
     GnState* d_state2 = nullptr;               // the chained loop ping-pongs between the two (GnBuffers below)
+    unsigned char* static_scratch = nullptr;   // this device's copy of g_static_scratch (ndt_align_static), resolved at ndt_create
     bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
     std::string err;
@@ -109,6 +110,35 @@ static int check_cfg(const ndt_config* c, std::string& err) {
     return NDT_OK;
 }
 
+// ---- ndt_align_static: the one entry point that allocates nothing (include/ndt_mi355.h).  Its Gauss-Newton loop keeps the
+// per-block partial rows (two buffers, the chained loop ping-pongs) and the two GnStates in this file-scope device array
+// instead of the handle's hipMalloc'd buffers.  The name below is a host-side stand-in, NOT a device address: every use
+// of the memory goes through the per-device pointer that hipGetSymbolAddress returns (each GPU holds its own copy).
+#define STATIC_MAX_ROWS 256                                        // one row per block, one block per CU on MI355X
+#define STATIC_ROWS_BYTES ((size_t)STATIC_MAX_ROWS * ACC_N * sizeof(double))   // 65 536
+#define STATIC_STATE_BYTES 512                                     // sizeof(GnState) = 424, padded to the array's alignment
+#define STATIC_SCRATCH_BYTES (2 * STATIC_ROWS_BYTES + 2 * STATIC_STATE_BYTES)  // 132 096 bytes per GPU, held until the process ends
+static_assert(sizeof(GnState) <= STATIC_STATE_BYTES, "GnState must fit its scratch cell");
+static __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
+
+#define NDT_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[NDT_MAX_DEVICES];              // per device: resolved once, with that device current
+// device `dev` must be current
+static hipError_t static_scratch_for_device(int dev, unsigned char** out) {
+    if (dev < 0 || dev >= NDT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return hipSuccess;
+}
+
 // where one Gauss-Newton loop keeps its device-side working state: rows[2] are partial-row buffers (>= grid rows each),
 // st[2] the two states the chained loop ping-pongs between
 struct GnBuffers { double* rows[2]; GnState* st[2]; };
@@ -150,7 +180,8 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
         hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
         hipMalloc((void**)&h->d_state2, sizeof(GnState)) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
+        static_scratch_for_device(cfg->device, &h->static_scratch) != hipSuccess) {
         ndt_destroy(h);
         return nullptr;
     }
@@ -415,7 +446,8 @@ int ndt_source_cells(ndt_handle* h, const double T[16], int64_t* keys, uint8_t* 
     return NDT_OK;
 }
 
-// The Gauss-Newton loop of ndt_align over `src`, with its device-side working state in `B` (the handle's buffers) and `grid` rows per launch.
+// The Gauss-Newton loop of ndt_align over `src`, with its device-side working state in `B` (the handle's buffers, or the
+// static scratch of ndt_align_static) and `grid` rows per launch.
 static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffers& B, const double guess[16], ndt_result* out) {
     memset(out, 0, sizeof *out);
     state_from_T(h->h_state, guess);
@@ -505,6 +537,37 @@ int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
     if (!guess || !out) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
     return gn_loop(h, resident_source(h), residual_grid(h->n_src, h->n_cu), handle_buffers(h), guess, out);
+}
+
+// The entry point that allocates nothing (declared in include/ndt_mi355.h): ndt_align on a source the caller holds in HBM
+// as three float arrays, with the loop's partial rows and states in the static device array g_static_scratch (through the
+// per-device pointer resolved at ndt_create).  No hipMalloc / hipFree / allocating routine on this path.
+int ndt_align_static(ndt_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, const double guess[16], ndt_result* out) {
+    if (!h) return NDT_ERR_INVALID_ARG;
+    if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
+    if (!guess || !out || (n && (!d_x || !d_y || !d_z))) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
+    if (n > (size_t)NDT_STATIC_MAX_POINTS) {
+        h->err = "ndt_align_static: " + std::to_string(n) + " source points exceed NDT_STATIC_MAX_POINTS (" + std::to_string(NDT_STATIC_MAX_POINTS) +
+                 "); use ndt_set_source + ndt_align";
+        return NDT_ERR_CAPACITY;
+    }
+    if (h->comm) { h->err = "ndt_align_static does not run with a communicator attached (its all-reduce rows are allocated buffers)"; return NDT_ERR_INVALID_ARG; }
+    if (h->prof) { h->err = "ndt_align_static does not run with profiling enabled (the event pool allocates)"; return NDT_ERR_INVALID_ARG; }
+    if (!h->static_scratch) { h->err = "static scratch not resolved on this device"; return NDT_ERR_HIP; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    // rows of a launch: as ndt_align sizes them, within the scratch's 256 rows (on MI355X the two are the same number,
+    // so both entry points sum in the same order and return the same bits)
+    const int grid = std::min(residual_grid(n, h->n_cu), STATIC_MAX_ROWS);
+    unsigned char* base = h->static_scratch;               // the device address, never the array's name
+    GnBuffers B;
+    B.rows[0] = (double*)base;
+    B.rows[1] = (double*)(base + STATIC_ROWS_BYTES);
+    B.st[0] = (GnState*)(base + 2 * STATIC_ROWS_BYTES);
+    B.st[1] = (GnState*)(base + 2 * STATIC_ROWS_BYTES + STATIC_STATE_BYTES);
+    // every call on this GPU shares the array and finds the last call's contents in it: the two states start at zero
+    // (the rows need no clearing: a launch writes each of its rows in full before any kernel reads them)
+    H_TRY(hipMemsetAsync(base + 2 * STATIC_ROWS_BYTES, 0, 2 * STATIC_STATE_BYTES, h->stream));
+    return gn_loop(h, SourceView{d_x, d_y, d_z, n}, grid, B, guess, out);
 }
 
 int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean, double* cov, double* info, uint8_t* valid,
