@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — NDT scan-matching throughput on MI355X (BASELINE.json metric).
 
-Workload (configs[2], the configuration the metric is quoted on): HDL-64-shaped scans (~118k points each)
-aligned against a GPU-resident voxel map built from a 2M-point keyframe map, NEARBY7, 1.0 m voxels, each
-from a perturbed ("IMU-predicted") pose with a fixed number of Gauss-Newton iterations (eps = 0, so no
-work can be skipped).  One step = one batched align of `--batch` independent scan-to-map pairs (offline
-replay; all scans resident in HBM).  value = source points x Gauss-Newton iterations per second, whole job.
-The online case (one scan at a time, what the SLAM pipeline does per frame) is timed too and reported in
-"single_scan" with its own roofline.
+Headline workload = BASELINE.json configs[2], the configuration the metric is quoted on, in its ONLINE form (what
+lio-slam's pipeline does per LiDAR frame, src/slam/src/process.cc:60-153): one HDL-64-shaped scan (~118k points) at a
+time is made the source, aligned against the GPU-resident voxel map of a 2M-point keyframe map (NEARBY7, 1.0 m voxels)
+from a perturbed ("IMU-predicted") pose with a fixed number of Gauss-Newton iterations (eps = 0, nothing can be skipped),
+and every `--keyframe-every`-th frame the aligned scan is merged into the resident map (incremental keyframe merge).
+One step = one frame.  All scans are resident in HBM before the timed region (as 12-byte xyz records; ndt_set_source
+reads them in place).  value = source points x Gauss-Newton iterations per second, whole job.
+Every timed align is checked against the CPU oracle replaying the same frames (a bounded prefix), outside the timed
+region: 1e-4 m / 1e-5 rad.
 
-N>1 (`torch.distributed.run`, one process per GPU): every rank holds a replica of the map and replays its
-own batch; no data-path collective; weak scaling.  `--mode sharded` instead shards one source cloud over
-the ranks with an RCCL all-reduce of the 29 H/b/chi2/n terms per iteration (configs[3]).
+Also reported in the same line: `replay` = configs[4]-style batched offline replay (a slice: `--batch` pairs per step),
+`large_map` = a 2M-point source against a 20M-point / >500k-voxel map whose table does not fit the L2 (the HBM-bound
+regime), `pcl_mode`, `cpu_baseline`.
+
+`--gpus N` with N > 1 starts N ranks itself (one process per GPU, `python -m torch.distributed.run`, 127.0.0.1) unless it
+already runs under such a launcher (RANK in the environment).  Default mode at N > 1: every rank replays its own frame
+stream against its own map replica — independent units, no data-path collective, weak scaling.  `--mode sharded` is
+configs[3]: ONE dense ~2M-point source cut over the ranks, an RCCL all-reduce of the 32-double H/b row per iteration
+(strong scaling); every rank must end at the identical pose, which is asserted.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import contextlib
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +40,29 @@ sys.path.insert(0, ROOT)
 
 DEFAULT_BATCH = 64      # pairs per step per GPU: configs[4] replays 4096 pairs over 8 GPUs (512 per GPU), a step is a slice of that
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock 2400 MHz
+VALU_PEAK = N_SIMD * CLOCK_HZ / 1e9      # G SIMD-cycles/s available for vector-instruction issue
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5    # BASELINE.json north_star: final poses within 1e-4 m / 1e-5 rad
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started by hand or by the driver: start N fresh rank processes (this parent has not touched the
+    GPU and never will), relay rank 0's one JSON line, fail if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit {p.returncode}); stdout was:\n{p.stdout[-2000:]}\n")
+        sys.exit(p.returncode or 1)
+    print(lines[-1], flush=True)
 
 
 @contextlib.contextmanager
@@ -51,14 +85,19 @@ def algorithmic_bytes_per_point(k, h):
     return 12.0 + 8.0 * k + 40.0 * h
 
 
-def measured_traffic(kernel, points_per_launch, field="bytes_per_launch"):
-    """HBM bytes per launch of `kernel` (or its L2 hit rate) from the committed rocprofv3 PMC passes
-    (profiles/traffic_r01.json); None when the file holds no measurement of a launch of this size."""
+def committed_counters():
+    """Per-launch hardware-counter figures of the kernels, from the committed rocprofv3 PMC passes of this round
+    (profiles/pmc_r02.json, written by tools/pmc_summary.py from tools/gpu_prof.sh's runs)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        return d[kernel][field] if d[kernel]["points_per_launch"] == int(points_per_launch) else None
-    except (OSError, KeyError, ValueError):
-        return None
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def pose_error(T, T_ref):
+    d = np.linalg.inv(T_ref) @ T
+    c = min(1.0, max(-1.0, (np.trace(d[:3, :3]) - 1.0) / 2.0))
+    return float(np.linalg.norm(d[:3, 3])), float(np.arccos(c))
 
 
 def load_workload(index, rank, world, dist, small):
@@ -68,7 +107,7 @@ def load_workload(index, rank, world, dist, small):
     if rank == 0 and not os.path.exists(path):
         c = synth.make_config(index, small=small)
         extra = {}
-        if index == 2:   # a few more scans along the trajectory: keyframes to merge, replay scans for other ranks
+        if index == 2:   # a few more scans along the trajectory: the frames of the stream, keyframes to merge, replay scans
             rng = np.random.Generator(np.random.PCG64(synth.seed_for(index) + 1000))
             n = len(c["poses"])
             for j in range(8):
@@ -106,26 +145,67 @@ def load_dense_workload(w, rank, world, dist):
     return d["map"], d["scan"]
 
 
+def large_map_workload():
+    """The HBM-bound regime: the 20 M-point, >500 k-voxel map of tests/test_gpu_scale.py (the 200 k-point yard map tiled
+    10 x 10 at 300 m pitch with 1 cm jitter; its voxel table, ghosts included, is > 100 MB: no L2 holds it) and a 2 M-point
+    source that touches ALL of it (a sixth of the scan seen from every tile, in one sensor frame).  Cached under /tmp."""
+    from lio_slam_amd import synth
+    path = "/tmp/ndt_bench_large.npz"
+    if not os.path.exists(path):
+        c = synth.make_config(2, small=True)
+        rng = np.random.default_rng(5)
+        tiles, parts = [], []
+        T = c["T_true"]
+        sub = c["scan"][::6]
+        for ix in range(10):
+            for iy in range(10):
+                off = np.array([300.0 * ix, 300.0 * iy, 0.0], np.float32)
+                t = c["map"] + off
+                tiles.append((t + rng.normal(0, 0.01, t.shape)).astype(np.float32))
+                wpts = synth.transform(T, sub) + off
+                parts.append(((wpts.astype(np.float64) - T[:3, 3]) @ T[:3, :3]).astype(np.float32))
+        tmp = path + f".{os.getpid()}.npz"
+        np.savez(tmp, map=np.concatenate(tiles), scan=np.concatenate(parts), T_true=T, guess=c["guess"])
+        os.replace(tmp, path)
+    return dict(np.load(path))
+
+
+class DeviceCloud:
+    """A cloud the CALLER holds in HBM (hipMalloc through ctypes), as packed 12-byte xyz records."""
+    _hip = None
+
+    def __init__(self, pts):
+        if DeviceCloud._hip is None:
+            DeviceCloud._hip = ctypes.CDLL("libamdhip64.so")
+        a = np.ascontiguousarray(pts, np.float32)
+        self.n, self.ptr = len(a), ctypes.c_void_p()
+        if self._hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(max(a.nbytes, 16))) != 0:
+            raise MemoryError("hipMalloc")
+        if self._hip.hipMemcpy(self.ptr, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) != 0:
+            raise RuntimeError("hipMemcpy")
+
+    def view(self):
+        return (self.ptr.value, self.n, 12)
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+
 def time_resident_build(ndt, pts, reps=5):
     """Map build with the target cloud already in HBM (handed over as a device pointer): the kernels and their host
     synchronisations without the PCIe copy.  Returns (ms, radix passes)."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    a = np.ascontiguousarray(pts, np.float32)
-    d = ctypes.c_void_p()
-    if hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(a.nbytes)) != 0:
-        return None, 0
+    d = DeviceCloud(pts)
     try:
-        if hip.hipMemcpy(d, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) != 0:
-            return None, 0
         best = None
         for _ in range(reps + 1):
-            t0 = time.perf_counter(); ndt.set_target((d.value, len(a), 12)); ndt.synchronize()
+            t0 = time.perf_counter(); ndt.set_target(d.view()); ndt.synchronize()
             ms = 1e3 * (time.perf_counter() - t0)
             best = ms if best is None else min(best, ms)
         return best, ndt.last_radix_passes()
     finally:
-        hip.hipFree(d)
+        d.free()
 
 
 def build_roofline(n_points, n_voxels, passes, ms):
@@ -137,6 +217,33 @@ def build_roofline(n_points, n_voxels, passes, ms):
     ach = algo / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "ms": ms, "radix_passes": passes,
             "bytes_per_point": 36.0 + 24.0 * passes, "points": int(n_points), "what": "whole ndt_set_target call, target cloud resident in HBM"}
+
+
+def residual_roofline(kernel, n_pts, k, hits, us, counters):
+    """Roofline object of a residual-kernel launch, timed live (`us`).  When the launch's voxel table is cache-resident
+    (measured HBM traffic a few per cent of the algorithmic bytes) what binds is vector-instruction issue: bound "valu",
+    achieved = VALU wave-instructions per launch (committed PMC pass, per point, x points) x 4 cycles / live duration,
+    against 1024 SIMDs x 2.4 GHz.  The HBM view stays beside it: measured traffic / time / 8 TB/s, and the algorithmic
+    bytes per second as an absolute figure (never as a fraction: served from L2 it can exceed the HBM peak)."""
+    bpp = algorithmic_bytes_per_point(k, hits)
+    c = counters.get(kernel, {})
+    out = {"kernel": kernel, "kernel_avg_us": us, "points_per_launch": int(n_pts), "hits_per_point": hits, "bytes_per_point": bpp,
+           "algorithmic_GBps": n_pts * bpp / (us * 1e-6) / 1e9,
+           "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"}
+    traffic = c.get("hbm_bytes_per_point")
+    out["traffic"] = None if traffic is None else traffic * n_pts
+    out["hbm_frac_measured"] = None if traffic is None else traffic * n_pts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+    out["l2_hit_rate"] = c.get("l2_hit_rate")
+    vpp = c.get("valu_insts_per_point")            # wave-instructions x 64 lanes / points: lane-instructions per point
+    if vpp is not None:
+        ach = vpp * n_pts / 64.0 * 4.0 / (us * 1e-6) / 1e9
+        out.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK, "unit": "G SIMD-cycles/s", "frac": ach / VALU_PEAK,
+                    "valu_lane_insts_per_point": vpp, "valu_busy_profiled": c.get("valu_busy"),
+                    "counters_source": "profiles/pmc_r02.json (rocprofv3 --pmc passes of tools/gpu_prof.sh, same workload)",
+                    "how": "SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x live kernel time)"})
+    else:
+        out.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK, "unit": "G SIMD-cycles/s", "frac": None})
+    return out
 
 
 def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
@@ -170,16 +277,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--iters", type=int, default=10, help="Gauss-Newton iterations per align (fixed)")
     ap.add_argument("--nearby", type=int, default=7)
-    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="scan-to-map pairs aligned together per step (replay mode)")
-    ap.add_argument("--mode", choices=["replay", "sharded"], default="replay")
+    ap.add_argument("--keyframe-every", type=int, default=10, help="online mode: every k-th frame is merged into the map")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="scan-to-map pairs aligned together per step (replay section)")
+    ap.add_argument("--mode", choices=["online", "sharded"], default="online")
     ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the oracle accuracy gate")
+    ap.add_argument("--no-extras", action="store_true", help="skip the replay / large-map / PCL-mode sections")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:       # decided before anything touches the GPU in this process
+        launch_ranks(a.gpus, sys.argv[1:])
+        return
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    devices_visible = None
     if use_dist:
         # rendezvous / barriers / timing reductions on CPU tensors (gloo); the data-path collective, where the
         # mode has one, is RCCL inside libndt_mi355.so on the handle's own stream
@@ -190,14 +304,15 @@ def main():
         with stdout_to_stderr():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
-        ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if ndev:
-            local %= ndev                         # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
+        devices_visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if devices_visible:
+            local %= devices_visible                # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
     import lio_slam_amd as la
     from lio_slam_amd import synth
 
     w = load_workload(2, rank, world if use_dist else 1, dist, a.small)
     ndt = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+    counters = committed_counters()
 
     def barrier():
         ndt.synchronize()
@@ -221,73 +336,115 @@ def main():
     n_vox = ndt.num_voxels(); n_map = len(w["map"])
     rb_ms, rb_passes = time_resident_build(ndt, w["map"])
     build_rl = build_roofline(len(w["map"]), n_vox, rb_passes, rb_ms)
-    merge_ms = []
-    for j in range(2):       # incremental keyframe merge (configs[2]): two keyframes into the resident map
-        t0 = time.perf_counter(); ndt.add_target(w[f"scan{j}"], w[f"T{j}"]); ndt.synchronize()
-        merge_ms.append(1e3 * (time.perf_counter() - t0))
+    extras = rank == 0 and world == 1 and not a.no_extras
+    out = {}
 
-    # ---- the online case: ONE scan aligned at a time (what lio-slam's pipeline does per LiDAR frame)
-    single = None
-    if a.mode == "replay":
-        ndt.set_source(w["scan"])
-        n1 = ndt.source_size()
-        for _ in range(a.warmup):
-            r1 = ndt.align(w["guess"])
-        ndt.synchronize()
-        reps1 = max(20, a.steps)
+    if a.mode == "online":
+        # ---- the headline: a stream of LiDAR frames, one scan at a time, a keyframe merge every k-th frame
+        scans = [w[f"scan{j}"] for j in range(8)]
+        dev = [DeviceCloud(s) for s in scans]                                   # resident in HBM before the timed region
+        g16 = [np.ascontiguousarray(w[f"guess{j}"].T).reshape(16) for j in range(8)]
+        Tk16 = [np.ascontiguousarray(w[f"T{j}"].T).reshape(16) for j in range(8)]
+        L = la.lib(); h = ndt._h
+        res = la.Result()
+        n_frames = a.warmup + a.steps
+        n_gate = 0 if a.no_cpu or rank != 0 else min(a.steps, max(12, a.keyframe_every + 2))
+        gate_T = []
+        merge_us, merges, pts_done = [], 0, 0.0
+
+        def frame(f, timed):
+            nonlocal merges, pts_done
+            j = (f + rank) % 8
+            rc = L.ndt_set_source(h, dev[j].ptr, dev[j].n, 12)
+            rc = rc or L.ndt_align(h, g16[j].ctypes.data, ctypes.byref(res))
+            if rc:
+                raise la.NdtError(rc, L.ndt_last_error(h).decode())
+            if timed:
+                pts_done += dev[j].n
+                if res.iterations != a.iters:
+                    raise RuntimeError("an align did not run its fixed iterations")
+                if f - a.warmup < n_gate:
+                    gate_T.append(np.array(res.T).reshape(4, 4).T.copy())
+            if f % a.keyframe_every == a.keyframe_every - 1:                   # keyframe: the resident source joins the map
+                t1 = time.perf_counter()
+                rc = L.ndt_add_target_from_source(h, Tk16[j].ctypes.data)
+                if rc:
+                    raise la.NdtError(rc, L.ndt_last_error(h).decode())
+                if timed:
+                    merges += 1
+                    merge_us.append(1e6 * (time.perf_counter() - t1))
+
+        for f in range(a.warmup):
+            frame(f, False)
+        barrier()
         t0 = time.perf_counter()
-        for _ in range(reps1):
-            r1 = ndt.align(w["guess"])
+        for f in range(a.warmup, n_frames):
+            frame(f, True)
         ndt.synchronize()
-        el1 = time.perf_counter() - t0
-        k1 = 0.5 * (ndt.time_residual(w["guess"], 300) + ndt.time_residual(r1["T"], 300))
-        ndt.profile(True); ndt.eval(w["guess"]); ndt.eval(r1["T"]); h1 = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
-        ach1 = n1 * algorithmic_bytes_per_point(a.nearby, h1) / (k1 * 1e-6) / 1e9
-        single = {"value": n1 * a.iters * reps1 / el1, "unit": "source-points*iters/s", "ms_per_align": 1e3 * el1 / reps1,
-                  "scans_per_s": reps1 / el1, "source_points": int(n1),
-                  "final_pose_error_m": float(np.linalg.norm((np.linalg.inv(w["T_true"]) @ r1["T"])[:3, 3])),
-                  "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
-                               "traffic": measured_traffic(f"k_residual<{a.nearby}>", n1),
-                               "l2_hit_rate": measured_traffic(f"k_residual<{a.nearby}>", n1, "l2_hit_rate"),
-                               "kernel": f"k_residual<{a.nearby}>", "kernel_avg_us": k1, "points_per_launch": int(n1),
-                               "hits_per_point": h1, "bytes_per_point": algorithmic_bytes_per_point(a.nearby, h1)}}
+        el = allmax(time.perf_counter() - t0)
+        pts_all = allsum(pts_done)
+        value = pts_all * a.iters / el
+        n1 = dev[0].n
+        last_T = np.array(res.T).reshape(4, 4).T.copy()
+        jl = (n_frames - 1 + rank) % 8
+        final_err = pose_error(last_T, w[f"T{jl}"])[0]
 
-    # ---- PCL compatibility mode: the objective / optimiser the reference's PCL build runs, on the
-    # same scan and map, with the reference's own parameters (process.cc:373-376: <= 35 iterations, eps 0.01, step 0.1)
-    pcl = None
-    if a.mode == "replay" and world == 1:
-        ndt_p = la.NDT(device=local, max_iterations=35, eps=0.01)
-        ndt_p.load_map(ndt.save_map()); ndt_p.set_source(w["scan"])
-        pvec = la.pcl_vector_from_matrix(w["guess"])
-        for _ in range(3):
-            rp = ndt_p.pcl_align(w["guess"])
-        repsp = max(20, a.steps); t0 = time.perf_counter()
-        for _ in range(repsp):
-            rp = ndt_p.pcl_align(w["guess"])
-        elp = time.perf_counter() - t0
-        usp, vxp, nbp = ndt_p.pcl_time_pass(pvec, hessian=True, reps=100)
-        bppp = 12 + 8 * 27 + 40 * vxp
-        achp = len(w["scan"]) * bppp / (usp * 1e-6) / 1e9
-        pcl = {"ms_per_align": 1e3 * elp / repsp, "iterations": rp["iterations"], "evaluations": rp["evaluations"],
-               "value": len(w["scan"]) * rp["evaluations"] * repsp / elp, "unit": "source-points*evaluations/s",
-               "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
-                            "kernel": "k_pcl_pass<hessian, gradient>", "kernel_avg_us": usp, "bytes_per_point": bppp,
-                            "voxels_met_per_point": vxp, "neighbours_per_point": nbp, "points_per_launch": int(len(w["scan"])),
-                            "algorithmic_bytes": "12 + 8*27 + 40*(valid voxels met in the 27 cells)"}}
-        if not a.no_cpu:
+        # accuracy gate (outside the timed region): the oracle replays the same frames from the start — same map, same
+        # merges at the same frames — and every gated align must land within 1e-4 m / 1e-5 rad of the oracle's pose
+        gate = None
+        if n_gate:
             from oracle.oracle import Oracle
-            o = Oracle(max_iterations=35, eps=0.01); o.set_target(w["map"]); o.set_source(w["scan"])
-            t0 = time.perf_counter(); ro = o.pcl_align(w["guess"]); elo = time.perf_counter() - t0
-            pcl["cpu_baseline"] = {"value": len(w["scan"]) * ro["evaluations"] / elo, "unit": "source-points*evaluations/s", "cores": 1,
-                                   "kind": "port", "ms_per_align": 1e3 * elo,
-                                   "sample": f"1 align ({ro['evaluations']} evaluations) of the same scan, oracle's PCL-literal restatement"}
-        ndt_p.close()
+            o = Oracle(nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+            o.set_threads(min(16, os.cpu_count() or 1))
+            o.set_target(w["map"])
+            worst = (0.0, 0.0)
+            for f in range(a.warmup + n_gate):
+                j = (f + rank) % 8
+                if f >= a.warmup:
+                    o.set_source(scans[j])
+                    ro = o.align(w[f"guess{j}"])
+                    dt, dr = pose_error(gate_T[f - a.warmup], ro["T"])
+                    worst = (max(worst[0], dt), max(worst[1], dr))
+                if f % a.keyframe_every == a.keyframe_every - 1:
+                    o.add_target(scans[j], w[f"T{j}"])
+            gate = {"frames_checked": n_gate, "max_translation_m": worst[0], "max_rotation_rad": worst[1], "tol_m": POSE_TOL_M,
+                    "tol_rad": POSE_TOL_RAD, "passed": bool(worst[0] < POSE_TOL_M and worst[1] < POSE_TOL_RAD),
+                    "against": "oracle/ndt_oracle.c replaying the same frames and keyframe merges from the same map"}
+            if not gate["passed"]:
+                raise SystemExit(f"accuracy gate failed: {gate}")
 
-    # ---- the timed workload
-    if a.mode == "sharded":
-        from lio_slam_amd.shard import shard_range
-        # configs[3]: ONE dense scan (128 rings x 15 625 azimuth steps, ~2 M returns, taken at the same pose in the same
+        # roofline of the dominant kernel (the chained residual + step launch, one per iteration): HIP events on the
+        # engine's stream around back-to-back launches of that kernel alone, right after the timed region
+        ndt.set_source(dev[0].view())
+        k_us = 0.5 * (ndt.time_chain(w["guess0"], 300) + ndt.time_chain(w["T0"], 300))
+        kp_us = 0.5 * (ndt.time_residual(w["guess0"], 300) + ndt.time_residual(w["T0"], 300))
+        ndt.profile(True); ndt.eval(w["guess0"]); ndt.eval(w["T0"]); h1 = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
+        kname = f"k_residual_chain<{a.nearby}>"
+        rl = residual_roofline(kname, n1, a.nearby, h1, k_us, counters)
+        rl["residual_pass_alone"] = residual_roofline(f"k_residual<{a.nearby}>", n1, a.nearby, h1, kp_us, counters)
+        out = {
+            "metric": "NDT source-points*iters/sec (120k-pt scan vs 2M-pt map)", "value": value, "unit": "source-points*iters/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("configs[2] online: one HDL-64-shaped scan (~118k pts) per step made the source and aligned against the "
+                                    f"GPU-resident voxel map of a 2M-pt keyframe map, keyframe merge every {a.keyframe_every} frames"
+                                    + (" (SMALL 200k-pt map: not a valid number)" if a.small else "")),
+                       "mode": "online", "frames_per_step_per_gpu": 1, "source_points_per_step_per_gpu": int(n1), "map_points": int(n_map),
+                       "voxels_at_start": int(n_vox), "voxels_at_end": int(ndt.num_voxels()), "nearby": a.nearby, "resolution_m": 1.0,
+                       "gn_iterations_per_align": a.iters, "keyframe_every": a.keyframe_every,
+                       "parallelism": f"frames{world}" if world > 1 else "1gpu",
+                       "multi_gpu": "each rank replays its own frame stream against its own map replica; no data-path collective"},
+            "scans_per_s": a.steps * world / el, "keyframe_merges_timed": merges,
+            "keyframe_merge_ms": (float(np.mean(merge_us)) / 1e3) if merge_us else None,
+            "map_build_ms": build_ms, "map_build_roofline": build_rl,
+            "roofline": rl, "accuracy_gate": gate, "final_pose_error_m": final_err,
+        }
+        for d in dev[1:]:
+            d.free()
+    else:
+        # ---- configs[3]: ONE dense scan (128 rings x 15 625 azimuth steps, ~2 M returns, taken at the same pose in the same
         # yard) against a 20 M-point map of that yard; the source is cut into contiguous ranges, one per rank
+        from lio_slam_amd.shard import shard_range
         guess, T = w["guess"], w["T_true"]
         big_map, scan_all = load_dense_workload(w, rank, world if use_dist else 1, dist)
         ndt.set_target(big_map); ndt.synchronize()
@@ -296,84 +453,162 @@ def main():
         rb_ms, rb_passes = time_resident_build(ndt, big_map)
         build_rl = build_roofline(n_map, n_vox, rb_passes, rb_ms); del big_map
         lo, hi = shard_range(len(scan_all), rank, world)
+        ranks_seen = 1
         if use_dist:
             with stdout_to_stderr():                             # RCCL prints its version banner on stdout
                 ids = [la.NDT.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 ndt.comm_init(rank, world, ids[0])
+            ranks_seen = ndt.comm_size()
         ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
         pts_rank = float(ndt.source_size())
-        step = lambda: ndt.align(guess)
-        check = lambda r: r["iterations"] == a.iters
-    else:
-        # offline replay of configs[2]-sized pairs: `batch` independent (scan, initial pose) pairs per step, each rank
-        # its own scans (8 distinct scans along the trajectory x hypotheses), all resident in HBM
-        rng = np.random.Generator(np.random.PCG64(synth.seed_for(2) + 77 + rank))
-        scans = [w[f"scan{(j + rank) % 8}"] for j in range(min(8, a.batch))]
-        pair_scan = [p % len(scans) for p in range(a.batch)]
-        guesses = [w[f"guess{(p % len(scans) + rank) % 8}"] if p < len(scans) else
-                   w[f"T{(p % len(scans) + rank) % 8}"] @ synth.perturbation(rng) for p in range(a.batch)]
-        guesses = np.stack(guesses); pair_scan = np.asarray(pair_scan, np.int32)
-        ndt.set_batch_sources(scans)                          # resident in HBM before the timed region
-        pts_rank = float(sum(len(scans[s]) for s in pair_scan))
-        step = lambda: ndt.align_batch_resident(guesses, pair_scan)
-        check = lambda r: all(x["iterations"] == a.iters and x["status"] == 0 for x in r)
-
-    for _ in range(a.warmup):
-        r = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        r = step()
-    ndt.synchronize()
-    el = allmax(time.perf_counter() - t0)
-    assert check(r), "an align did not run its fixed iterations"
-    pts_all = allsum(pts_rank)
-    value = pts_all * a.iters * a.steps / el
-
-    # roofline of the dominant kernel: HIP events on the engine's stream around back-to-back launches of that
-    # kernel alone, right after the timed region (kept outside it so that `value` is undisturbed)
-    if a.mode == "sharded":
+        for _ in range(a.warmup):
+            r = ndt.align(guess)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r = ndt.align(guess)
+        ndt.synchronize()
+        el = allmax(time.perf_counter() - t0)
+        assert r["iterations"] == a.iters, "an align did not run its fixed iterations"
+        pts_all = allsum(pts_rank)
+        value = pts_all * a.iters * a.steps / el
+        identical = True
+        if use_dist:                                           # every rank took the same all-reduced steps: identical poses, bit for bit
+            import torch
+            mine = torch.from_numpy(np.ascontiguousarray(r["T"]).view(np.int64).reshape(-1).copy())
+            allT = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allT, mine)
+            identical = all(bool(torch.equal(t, allT[0])) for t in allT)
+            assert identical, "ranks ended at different poses"
         k_us = 0.5 * (ndt.time_residual(guess, 300) + ndt.time_residual(r["T"], 300))
-        ndt.profile(True); ndt.eval(guess); ndt.eval(r["T"]); h = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
-        ppl, kname = pts_rank, f"k_residual<{a.nearby}>"
-        err = [float(np.linalg.norm((np.linalg.inv(T) @ r["T"])[:3, 3]))]
-    else:
-        k_us, ppl, h = ndt.time_residual_batch(100)
-        kname = f"k_residual_batch<{a.nearby}>"
-        err = [float(np.linalg.norm((np.linalg.inv(w[f"T{(pair_scan[p] + rank) % 8}"]) @ r[p]["T"])[:3, 3])) for p in range(a.batch)]
-    bpp = algorithmic_bytes_per_point(a.nearby, h)
-    achieved = ppl * bpp / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
+        ndt.profile(True); ndt.eval(guess); ndt.eval(r["T"]); h1 = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
+        kname = f"k_residual<{a.nearby}>"
+        out = {
+            "metric": "NDT source-points*iters/sec (2M-pt source vs 20M-pt map, source sharded over the GPUs)", "value": value,
+            "unit": "source-points*iters/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[3]: ONE dense ~2M-point scan sharded over the ranks against the GPU-resident voxel map of a "
+                                   "20M-point map (replicated per rank), RCCL all-reduce of H,b per iteration",
+                       "mode": "sharded", "source_points_per_step_per_gpu": int(pts_rank), "source_points_total": int(pts_all),
+                       "map_points": int(n_map), "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0,
+                       "gn_iterations_per_align": a.iters, "parallelism": f"sharded{world}"},
+            "scans_per_s": a.steps / el, "poses_identical_across_ranks": identical,
+            "map_build_ms": build_ms, "map_build_roofline": build_rl,
+            "roofline": residual_roofline(kname, pts_rank, a.nearby, h1, k_us, counters),
+            "final_pose_error_m": pose_error(r["T"], T)[0],
+        }
+    if devices_visible is not None:
+        out["devices_visible"] = devices_visible
 
-    out = {
-        "metric": "NDT source-points*iters/sec (120k-pt scans vs 2M-pt map)", "value": value, "unit": "source-points*iters/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
-        "higher_is_better": True, "scaling": "weak" if a.mode == "replay" else "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (("configs[2]: HDL-64-shaped scans (~118k pts) vs the GPU-resident voxel map of a 2M-pt keyframe map"
-                                 f"; offline replay, {a.batch} independent scan-to-map pairs per step per GPU") if a.mode == "replay"
-                                else ("configs[3]: ONE dense ~2M-point scan sharded over the ranks against the GPU-resident voxel map of a "
-                                      "20M-point map (replicated per rank), RCCL all-reduce of H,b per iteration")
-                                ) + (" (SMALL 200k-pt map: not a valid number)" if a.small else ""),
-                   "mode": a.mode, "pairs_per_step_per_gpu": a.batch if a.mode == "replay" else 1,
-                   "source_points_per_step_per_gpu": int(pts_rank), "map_points": int(n_map),
-                   "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0, "gn_iterations_per_align": a.iters,
-                   "parallelism": f"{a.mode}{world}"},
-        "scans_per_s": a.steps * (a.batch * world if a.mode == "replay" else 1) / el,
-        "map_build_ms": build_ms, "map_build_roofline": build_rl, "keyframe_merge_ms": merge_ms,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(kname, ppl), "l2_hit_rate": measured_traffic(kname, ppl, "l2_hit_rate"),
-                     "traffic_source": "profiles/traffic_r01.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE and TCC_HIT / TCC_MISS, separate passes, same workload)",
-                     "kernel": kname, "kernel_avg_us": k_us, "bytes_per_point": bpp, "hits_per_point": h,
-                     "points_per_launch": int(ppl),
-                     "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"},
-        "final_pose_error_m_max": max(err) if err else None,
-        "single_scan": single,
-        "pcl_mode": pcl,
-    }
+    if extras and a.mode == "online":
+        # ---- replay: configs[4]-style offline replay of configs[2]-sized pairs, `batch` independent (scan, initial pose)
+        # pairs per step, all scans resident in HBM
+        rng = np.random.Generator(np.random.PCG64(synth.seed_for(2) + 77))
+        scans = [w[f"scan{j}"] for j in range(min(8, a.batch))]
+        pair_scan = np.asarray([p % len(scans) for p in range(a.batch)], np.int32)
+        guesses = np.stack([w[f"guess{p % len(scans)}"] if p < len(scans) else w[f"T{p % len(scans)}"] @ synth.perturbation(rng)
+                            for p in range(a.batch)])
+        nr = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+        nr.set_target(w["map"])
+        nr.set_batch_sources(scans)
+        pts_step = float(sum(len(scans[s]) for s in pair_scan))
+        rsteps = max(5, min(a.steps, 40))
+        for _ in range(3):
+            r = nr.align_batch_resident(guesses, pair_scan)
+        nr.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(rsteps):
+            r = nr.align_batch_resident(guesses, pair_scan)
+        nr.synchronize()
+        elr = time.perf_counter() - t0
+        assert all(x["iterations"] == a.iters and x["status"] == 0 for x in r)
+        kb_us, ppl, hb = nr.time_residual_batch(100)
+        errs = [pose_error(r[p]["T"], w[f"T{pair_scan[p]}"])[0] for p in range(a.batch)]
+        # accuracy: a few pairs against the oracle
+        rgate = None
+        if not a.no_cpu:
+            from oracle.oracle import Oracle
+            o = Oracle(nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+            o.set_threads(min(16, os.cpu_count() or 1)); o.set_target(w["map"])
+            worst = (0.0, 0.0)
+            chk = sorted(set([0, 1, a.batch // 2, a.batch - 1]))
+            for p in chk:
+                o.set_source(scans[pair_scan[p]])
+                dt, dr = pose_error(r[p]["T"], o.align(guesses[p])["T"])
+                worst = (max(worst[0], dt), max(worst[1], dr))
+            rgate = {"pairs_checked": len(chk), "max_translation_m": worst[0], "max_rotation_rad": worst[1],
+                     "passed": bool(worst[0] < POSE_TOL_M and worst[1] < POSE_TOL_RAD)}
+            if not rgate["passed"]:
+                raise SystemExit(f"replay accuracy gate failed: {rgate}")
+        out["replay"] = {"value": pts_step * a.iters * rsteps / elr, "unit": "source-points*iters/s", "pairs_per_step": a.batch,
+                         "ms_per_step": 1e3 * elr / rsteps, "scans_per_s": a.batch * rsteps / elr, "steps": rsteps,
+                         "workload": f"configs[4] slice: {a.batch} independent configs[2]-sized scan-to-map pairs per batched align",
+                         "final_pose_error_m_max": max(errs), "accuracy_gate": rgate,
+                         "roofline": residual_roofline(f"k_residual_batch<{a.nearby}>", ppl, a.nearby, hb, kb_us, counters)}
+        nr.close()
+
+        # ---- large map: the regime the HBM roofline is about (table beyond every L2)
+        lm = large_map_workload()
+        nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+        t0 = time.perf_counter(); nl.set_target(lm["map"]); nl.synchronize(); lb_ms = 1e3 * (time.perf_counter() - t0)
+        lrb_ms, lrb_p = time_resident_build(nl, lm["map"], reps=2)
+        nl.set_source(lm["scan"])
+        nsrc = nl.source_size()
+        for _ in range(2):
+            rl_ = nl.align(lm["guess"])
+        nl.synchronize()
+        lsteps = 10
+        t0 = time.perf_counter()
+        for _ in range(lsteps):
+            rl_ = nl.align(lm["guess"])
+        nl.synchronize()
+        ell = time.perf_counter() - t0
+        kl_us = 0.5 * (nl.time_residual(lm["guess"], 50) + nl.time_residual(rl_["T"], 50))
+        nl.profile(True); nl.eval(lm["guess"]); nl.eval(rl_["T"]); hl = nl.profile_read()["hits_per_point"]; nl.profile(False)
+        bppl = algorithmic_bytes_per_point(a.nearby, hl)
+        achl = nsrc * bppl / (kl_us * 1e-6) / 1e9
+        cl = counters.get(f"k_residual<{a.nearby}>@large_map", {})
+        tr = cl.get("hbm_bytes_per_point")
+        out["large_map"] = {"value": nsrc * a.iters * lsteps / ell, "unit": "source-points*iters/s", "ms_per_align": 1e3 * ell / lsteps,
+                            "workload": "2M-pt source touching all of a 20M-pt / >500k-voxel map (tests/test_gpu_scale.py's tiled yard): "
+                                        "voxel table beyond every L2",
+                            "source_points": int(nsrc), "map_points": int(len(lm["map"])), "voxels": int(nl.num_voxels()),
+                            "map_build_ms": lb_ms, "map_build_roofline": build_roofline(len(lm["map"]), nl.num_voxels(), lrb_p, lrb_ms),
+                            "roofline": {"bound": "hbm", "achieved": achl, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achl / HBM_PEAK_GBS,
+                                         "traffic": None if tr is None else tr * nsrc,
+                                         "traffic_over_algorithmic": None if tr is None else tr / bppl,
+                                         "hbm_frac_measured": None if tr is None else tr * nsrc / (kl_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                         "l2_hit_rate": cl.get("l2_hit_rate"),
+                                         "kernel": f"k_residual<{a.nearby}>", "kernel_avg_us": kl_us, "points_per_launch": int(nsrc),
+                                         "hits_per_point": hl, "bytes_per_point": bppl,
+                                         "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"}}
+        nl.close()
+
+        # ---- PCL compatibility mode: the objective / optimiser the reference's PCL build runs, on the
+        # same scan and map, with the reference's own parameters (process.cc:373-376: <= 35 iterations, eps 0.01, step 0.1)
+        ndt_p = la.NDT(device=local, max_iterations=35, eps=0.01)
+        ndt_p.set_target(w["map"]); ndt_p.set_source(w["scan"])
+        pvec = la.pcl_vector_from_matrix(w["guess"])
+        for _ in range(3):
+            rp = ndt_p.pcl_align(w["guess"])
+        repsp = 20; t0 = time.perf_counter()
+        for _ in range(repsp):
+            rp = ndt_p.pcl_align(w["guess"])
+        elp = time.perf_counter() - t0
+        usp, vxp, nbp = ndt_p.pcl_time_pass(pvec, hessian=True, reps=100)
+        bppp = 12 + 8 * 27 + 40 * vxp
+        out["pcl_mode"] = {"ms_per_align": 1e3 * elp / repsp, "iterations": rp["iterations"], "evaluations": rp["evaluations"],
+                           "value": len(w["scan"]) * rp["evaluations"] * repsp / elp, "unit": "source-points*evaluations/s",
+                           "kernel": "k_pcl_pass<hessian, gradient>", "kernel_avg_us": usp, "bytes_per_point": bppp,
+                           "algorithmic_GBps": len(w["scan"]) * bppp / (usp * 1e-6) / 1e9, "voxels_met_per_point": vxp,
+                           "neighbours_per_point": nbp, "points_per_launch": int(len(w["scan"]))}
+        ndt_p.close()
+
     if rank == 0 and world == 1 and not a.no_cpu:
         out.update(time_cpu_baseline(w, a.iters, a.nearby))
-        out["gpu_over_cpu1"] = value / out["cpu_baseline"]["value"]
+        out["gpu_over_cpu1"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     ndt.close()

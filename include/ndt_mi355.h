@@ -276,6 +276,8 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
 int ndt_comm_unique_id(char id_out[128]);
 int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]);
 int ndt_comm_destroy(ndt_handle* h);
+/* Ranks of the attached communicator as RCCL counts them (1 when none is attached): what bench.py reports as ranks_seen. */
+int ndt_comm_size(const ndt_handle* h);
 
 /* Several GPUs in ONE process (SURVEY.md §8(b) "multi-GPU: ndt_create_group(n_dev, dev_ids)"; the replay half of
  * §8(e)): a group is one member handle per entry of dev_ids (cfg->device is ignored; a device may be listed more than
@@ -306,6 +308,10 @@ int ndt_profile_read(ndt_handle* h, double* residual_kernel_us, int64_t* residua
 /* Mean duration of the residual kernel alone: `reps` back-to-back launches at pose T between two HIP events on
  * the handle's stream (what bench.py's roofline uses; agrees with rocprofv3 --kernel-trace). */
 int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_per_launch);
+
+/* The same for the launch the single-scan Gauss-Newton loop actually makes per iteration (k_residual_chain: the previous
+ * launch's reduction + step in the prologue, then the residual pass), `reps` of them back to back from pose T. */
+int ndt_time_chain(ndt_handle* h, const double T[16], int reps, double* us_per_launch);
 
 /* The same for the batched residual kernel, on the batch left resident by the last ndt_align_batch (poses as
  * that call left them).  points_per_launch / hits_per_point may be NULL. */

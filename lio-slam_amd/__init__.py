@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_align_static", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
-    "ndt_comm_init", "ndt_comm_destroy", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_comm_size", "ndt_time_chain", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version", "ndt_last_radix_passes",
     "ndt_create_group", "ndt_destroy_group", "ndt_group_size", "ndt_group_handle", "ndt_group_set_target", "ndt_group_add_target",
     "ndt_group_align_batch", "ndt_group_last_error",
@@ -137,6 +137,8 @@ def lib():
     L.ndt_comm_unique_id.argtypes = [vp]
     L.ndt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ndt_comm_destroy.argtypes = [vp]
+    L.ndt_comm_size.argtypes = [vp]
+    L.ndt_time_chain.argtypes = [vp, vp, C.c_int, vp]
     L.ndt_profile.argtypes = [vp, C.c_int]
     L.ndt_profile_read.argtypes = [vp, vp, vp, vp]
     L.ndt_time_residual.argtypes = [vp, vp, C.c_int, vp]
@@ -479,6 +481,12 @@ class NDT:
         self._chk(lib().ndt_time_residual(self._h, t.ctypes.data, int(reps), C.addressof(us)))
         return us.value
 
+    def time_chain(self, T, reps=200):
+        """Mean microseconds of one chained launch of the single-scan loop (previous step + residual pass) from pose T."""
+        t = _T(T); us = C.c_double()
+        self._chk(lib().ndt_time_chain(self._h, t.ctypes.data, int(reps), C.addressof(us)))
+        return us.value
+
     def time_residual_batch(self, reps=100):
         """(us per launch, points per launch, hits per point) of the batched residual kernel on the resident batch."""
         us = C.c_double(); pts = C.c_double(); hp = C.c_double()
@@ -501,6 +509,8 @@ class NDT:
         self._chk(lib().ndt_comm_init(self._h, rank, n_ranks, buf))
 
     def comm_destroy(self): self._chk(lib().ndt_comm_destroy(self._h))
+
+    def comm_size(self): return lib().ndt_comm_size(self._h)
 
 
 def information_from_hessian(H, scale=1.0, rel_floor=1e-6):

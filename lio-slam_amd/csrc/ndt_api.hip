@@ -21,12 +21,14 @@ struct ndt_nccl_id { char internal[128]; };
 typedef int (*pfn_ncclCommInitRank)(void**, int, ndt_nccl_id, int);
 typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*pfn_ncclCommDestroy)(void*);
+typedef int (*pfn_ncclCommCount)(const void*, int*);
 static struct {
     void* lib;
     pfn_ncclGetUniqueId get_id;
     pfn_ncclCommInitRank init_rank;
     pfn_ncclAllReduce all_reduce;
     pfn_ncclCommDestroy destroy;
+    pfn_ncclCommCount count;
 } g_rccl;
 static bool rccl_load() {
     static std::once_flag once;        // handles on several host threads may reach this together
@@ -42,6 +44,7 @@ static bool rccl_load() {
         g_rccl.init_rank = (pfn_ncclCommInitRank)dlsym(lib, "ncclCommInitRank");
         g_rccl.all_reduce = (pfn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
         g_rccl.destroy = (pfn_ncclCommDestroy)dlsym(lib, "ncclCommDestroy");
+        g_rccl.count = (pfn_ncclCommCount)dlsym(lib, "ncclCommCount");
         g_rccl.lib = lib;
     });
     return g_rccl.lib && g_rccl.get_id && g_rccl.init_rank && g_rccl.all_reduce && g_rccl.destroy;
@@ -91,6 +94,12 @@ struct ndt_handle {
 
 #define H_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
 
+// true when p is device memory of device `dev` (a plain host pointer makes the query fail: that is not an error)
+static bool points_on_device(const void* p, int dev) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice && at.device == dev;
+}
 static KeyParams key_params(const ndt_config& c) {
     KeyParams kp;
     kp.inv_leaf_f32 = 1.0f / c.resolution;
@@ -249,11 +258,17 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 source points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
-    H_TRY(h->sraw.ensure(n * stride + 16));
     H_TRY(h->sx.ensure(n * 4 + 16)); H_TRY(h->sy.ensure(n * 4 + 16)); H_TRY(h->sz.ensure(n * 4 + 16));
     if (n) {
-        H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
-        H_TRY(unpack_points_soa(h->sraw.p, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
+        // records already in this device's memory are unpacked in place (the unpack kernel is their only reader and has
+        // finished when this call returns); host records are staged through sraw
+        const void* d_in = pts;
+        if (!points_on_device(pts, h->cfg.device)) {
+            H_TRY(h->sraw.ensure(n * stride + 16));
+            H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
+            d_in = h->sraw.p;
+        }
+        H_TRY(unpack_points_soa(d_in, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
     }
     H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
     H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
@@ -939,6 +954,12 @@ int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]) {
     H_TRY(hipMemsetAsync(h->comm_rows.p, 0, 2 * ACC_N * sizeof(double), h->stream));
     return NDT_OK;
 }
+int ndt_comm_size(const ndt_handle* h) {      // ranks of the attached communicator, as RCCL counts them (1 without one)
+    if (!h || !h->comm) return 1;
+    int n = 0;
+    if (!g_rccl.count || g_rccl.count(h->comm, &n) != 0) return h->n_ranks;
+    return n;
+}
 int ndt_comm_destroy(ndt_handle* h) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if (h->comm) { (void)hipStreamSynchronize(h->stream); g_rccl.destroy(h->comm); h->comm = nullptr; h->n_ranks = 1; }
@@ -982,6 +1003,47 @@ int ndt_time_residual(ndt_handle* h, const double T[16], int reps, double* us_pe
     float ms = 0.f;
     H_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_per_launch = 1e3 * (double)ms / reps;
+    return NDT_OK;
+}
+
+// the chained launch of the single-scan loop (previous step in the prologue + residual pass), back to back: launch i
+// reduces launch i - 1's rows, takes the step and evaluates at the new pose, exactly as inside ndt_align, with the
+// iteration cap and eps lifted so that the state never finishes
+int ndt_time_chain(ndt_handle* h, const double T[16], int reps, double* us_per_launch) {
+    int rc = ready(h);
+    if (rc != NDT_OK) return rc;
+    if (!T || reps < 1 || !us_per_launch || !h->n_src) { h->err = "bad argument"; return NDT_ERR_INVALID_ARG; }
+    H_TRY(hipSetDevice(h->cfg.device));
+    const int grid = residual_grid(h->n_src, h->n_cu);
+    if (grid > h->n_cu) { h->err = "the chained launch is not used for a source of this size"; return NDT_ERR_INVALID_ARG; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    H_TRY(hipEventCreate(&e0)); H_TRY(hipEventCreate(&e1));
+    GnState init;
+    state_from_T(&init, T);
+    const EvalParams ep = eval_params(h);
+    SolveParams sp = solve_params(h);
+    sp.eps = 0.0; sp.max_iterations = 0x7fffffff;
+    const GnBuffers B = handle_buffers(h);
+    int cur = 0, rcur = 0;
+    bool first = true;
+    auto pass = [&]() {
+        launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
+                              B.st[cur], B.st[cur ^ 1], B.rows[rcur ^ 1], first ? 0 : grid, sp, ep, B.rows[rcur], grid, h->use_links, first ? &init : nullptr,
+                              h->stream);
+        first = false; cur ^= 1; rcur ^= 1;
+    };
+    for (int i = 0; i < 3; ++i) pass();   // warm
+    H_TRY(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) pass();
+    H_TRY(hipEventRecord(e1, h->stream));
+    H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+    H_TRY(hipEventSynchronize(e1));
+    H_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    H_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (h->h_state->done) { h->err = "the timed loop stopped (too few residuals or a singular Hessian at this pose)"; return h->h_state->status ? h->h_state->status : NDT_ERR_INVALID_ARG; }
     *us_per_launch = 1e3 * (double)ms / reps;
     return NDT_OK;
 }
