@@ -82,6 +82,23 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 // of partials and a single block folds the rows.
 #define TK_MAX_BLOCKS 1024
 // Input is AoS records (raw, stride) or, when stride == 0, three SoA arrays (raw = x, soa_y, soa_z).
+// one input point: AoS record or SoA arrays, optional keyframe transform (pcl::transformPointCloud, process.cc:134-136:
+// float64 math, one rounding to float32), PCL's cell rule.  Returns false for a dropped point (non-finite / out of key range).
+__device__ __forceinline__ bool load_target_point(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t i, size_t stride, int has_T,
+                                                  const double* Rt, const KeyParams& kp, float& x, float& y, float& z, int32_t c[3]) {
+    if (stride) { const float* p = (const float*)(raw + i * stride); x = p[0]; y = p[1]; z = p[2]; }
+    else { x = ((const float*)raw)[i]; y = soa_y[i]; z = soa_z[i]; }
+    bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+    if (ok && has_T) {
+        double q[3];
+        ndt_xform(Rt, Rt + 9, x, y, z, q);
+        x = (float)q[0]; y = (float)q[1]; z = (float)q[2];
+    }
+    return ok && ndt_target_cell(kp, x, y, z, c);
+}
+
+// WRITE = false: bounding box and valid count only (the fast path reads the input a second time in k_make_elems32)
+template <bool WRITE>
 __global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, const double* Rt,
                                                      KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
                                                      int32_t* block_rows) {
@@ -92,19 +109,13 @@ __global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, c
     int32_t okc = 0, mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float x, y, z;
-        if (stride) { const float* p = (const float*)(raw + i * stride); x = p[0]; y = p[1]; z = p[2]; }
-        else { x = ((const float*)raw)[i]; y = soa_y[i]; z = soa_z[i]; }
-        bool ok = isfinite(x) && isfinite(y) && isfinite(z);
-        if (ok && has_T) {   // pcl::transformPointCloud (process.cc:134-136): float64 math, one rounding to float32
-            double q[3];
-            ndt_xform(Rt, Rt + 9, x, y, z, q);
-            x = (float)q[0]; y = (float)q[1]; z = (float)q[2];
-        }
         int32_t c[3];
-        ok = ok && ndt_target_cell(kp, x, y, z, c);
-        tx[i] = x; ty[i] = y; tz[i] = z;
-        vals[i] = (uint32_t)i;
-        keys[i] = ok ? ndt_pack(c[0], c[1], c[2]) : NDT_KEY_EMPTY;
+        const bool ok = load_target_point(raw, soa_y, soa_z, i, stride, has_T, Rt, kp, x, y, z, c);
+        if (WRITE) {
+            tx[i] = x; ty[i] = y; tz[i] = z;
+            vals[i] = (uint32_t)i;
+            keys[i] = ok ? ndt_pack(c[0], c[1], c[2]) : NDT_KEY_EMPTY;
+        }
         if (ok) {
             okc += 1;
 #pragma unroll
@@ -657,39 +668,6 @@ __device__ inline bool neighbour_key(int64_t key, int d, int64_t* out) {   // d:
     *out = ndt_pack(c[0], c[1], c[2]);
     return true;
 }
-// per batch voxel: how many of its six neighbours are not in the table yet (an upper bound of the ghosts to add)
-// the batch's voxels come either as sorted segments (sk, seg_start, km) or as a plain key list (plain != nullptr)
-__global__ void k_ghost_count(const uint64_t* sk, const uint32_t* seg_start, const int64_t* plain, uint32_t nseg, SortKeyMap km, const int64_t* keys,
-                              uint64_t mask, uint32_t* missing) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nseg) return;
-    const int64_t key = plain ? plain[g] : sortkey_to_packed(sk[seg_start[g]], km);
-    uint32_t n = 0;
-    for (int d = 0; d < 6; ++d) {
-        int64_t nk;
-        if (neighbour_key(key, d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++n;
-    }
-    missing[g] = n;
-}
-__global__ void k_ghost_insert(const uint64_t* sk, const uint32_t* seg_start, const int64_t* plain, uint32_t nseg, SortKeyMap km, int64_t* keys,
-                               uint64_t mask, uint32_t* inserted) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nseg) return;
-    const int64_t key = plain ? plain[g] : sortkey_to_packed(sk[seg_start[g]], km);
-    uint32_t n = 0;
-    for (int d = 0; d < 6; ++d) {
-        int64_t nk;
-        if (!neighbour_key(key, d, &nk)) continue;
-        uint64_t slot = ndt_hash_key(nk) & mask;
-        for (;;) {
-            unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)nk);
-            if ((int64_t)prev == NDT_KEY_EMPTY) { ++n; if (slot < 4) keys[mask + 1 + slot] = nk; break; }   // slot is zeroed: a ghost
-            if ((int64_t)prev == nk) break;
-            slot = (slot + 1) & mask;
-        }
-    }
-    inserted[g] = n;
-}
 __global__ void k_link_all(const int64_t* keys, VoxSlot* slots, size_t cap) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
@@ -707,7 +685,8 @@ __global__ void k_link_all(const int64_t* keys, VoxSlot* slots, size_t cap) {
 
 static size_t pow2_at_least(size_t v) { size_t c = 1024; while (c < v) c <<= 1; return c; }
 
-// want_entries counts occupied slots (voxels + ghost cells)
+// want_entries counts occupied slots (voxels + ghost cells).  Growing moves every entry, so the neighbour links are
+// rebuilt over the whole new table (k_link_all): the only table-wide pass, and only when the capacity changes.
 static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::string& err) {
     size_t need = pow2_at_least(want_entries * 2);       // load factor <= 1/2
     if (m.cap >= need && !(m.n_entries == 0 && m.cap > 16 * need)) return NDT_OK;   // an empty, far too large table is re-made
@@ -718,7 +697,9 @@ static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::str
     if (m.cap) {
         k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.counts, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.counts, nm.mean,
                                                                 nm.cov, ncap - 1);
+        k_link_all<<<(unsigned)((ncap + 255) / 256), 256, 0, s>>>(nm.keys, nm.slots, ncap);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(nm.d_n_vox, m.d_n_vox, 8, hipMemcpyDeviceToDevice, s));     // the device-side counters move with the map
         nm.n_vox = m.n_vox; nm.n_entries = m.n_entries;
         HIP_TRY(hipStreamSynchronize(s));
         map_free(m);
@@ -729,58 +710,482 @@ static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::str
 
 static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; return b; }
 
-// After the voxels of a batch are in the table: count the new voxels / entries (flags written by the insert kernel),
-// add the ghost cells around the batch's voxels and rewrite the neighbour links.
-static int finish_entries(VoxelMap& m, MapWork& w, const uint64_t* sorted_keys, const uint32_t* segs, const int64_t* plain, uint32_t nseg,
-                          const SortKeyMap& km, hipStream_t s, std::string& err) {
-    int rc;
-    // sums of per-voxel flags (block sums + one-block spine; no scan-down needed): misc[8..11]
-    uint32_t* d_sums = (uint32_t*)(w.misc.as<int32_t>() + 8);
-    const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
-    const unsigned nbseg = (unsigned)((nseg + 255) / 256);
-    HIP_TRY(w.scan_tmp.ensure((nbf + 2) * 4));
-    auto sum_flags = [&](const uint32_t* f, uint32_t* out) {
-        k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(f, nseg, w.scan_tmp.as<uint32_t>());
-        k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, out);
-    };
-    sum_flags(w.flags.as<uint32_t>(), d_sums + 0);      // new voxels
-    sum_flags(w.flags2.as<uint32_t>(), d_sums + 1);     // new table entries
-    k_ghost_count<<<nbseg, 256, 0, s>>>(sorted_keys, segs, plain, nseg, km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
-    sum_flags(w.flags.as<uint32_t>(), d_sums + 2);      // neighbours not in the table yet (upper bound)
-    HIP_TRY(hipGetLastError());
-    uint32_t sums[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(sums, d_sums, 12, hipMemcpyDeviceToHost, s));
+// ------------------------------------------------------------------ plan / counter words
+// Everything the stages after the bounding box decide is decided on the DEVICE and read back once, at the end of the call:
+// w.misc (int32 words): [0..5] bbox, [6] n_valid, [7] nseg, [8..11] flag sums (64-bit-key path), [12] big segments,
+// [16..39] keyframe transform, [40..47] the words below.  VoxelMap::d_n_vox: [0] voxels with points, [1] table entries.
+#define PL_NSEG 7
+#define PL_BIGCOUNT 12
+#define PL_LANES 40      // lanes per segment in the sums (8 | 64)
+#define PL_BIG 41        // segments longer than this are summed by a whole block
+#define PL_ABORT1 42     // the batch's voxels may not fit the table: the insert stages did nothing, the host grows the table and re-runs them
+#define PL_ABORT2 43     // the ghost cells may not fit: the ghost stage did nothing, the host grows the table and re-runs it
+#define PL_MISSING 44    // neighbours of the batch's voxels that are not in the table (upper bound of the ghosts to add)
+#define PL_NEW_VOX 45    // voxels that got their first points
+#define PL_NEW_ENT 46    // table entries created for voxels
+#define PL_NEW_GHOST 47  // table entries created for ghost cells
+
+// block-wide sum of a per-thread count, added to *dst by one atomic per block (same-address atomics serialise)
+__device__ __forceinline__ void block_count_add(uint32_t v, int32_t* dst) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd((uint32_t*)dst, s_cnt);
+}
+
+// ------------------------------------------------------------------ fast path: compact keys of <= 32 bits
+// One 16-byte element {sort key, x, y, z} per point travels through the radix passes (one dwordx4 per lane), so the
+// per-voxel sums afterwards read their points as a contiguous stream instead of gathering them through a sorted index.
+
+// LDS histogram add with same-digit lanes of a wave combined first (a LiDAR ring's consecutive points share their digit:
+// plain LDS atomics would serialise 64 ways)
+__device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act) {
+    unsigned long long m = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot(act && ((d >> b) & 1u));
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const int lane = threadIdx.x & 63;
+    if (act && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(m));
+}
+
+template <int RS_ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T,
+                                                             const double* Rt, KeyParams kp, SortKeyMap km, uint32_t invalid_sk, uint4* elems, uint32_t* hist,
+                                                             unsigned nblk) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        const bool act = i < n;
+        uint32_t sk = invalid_sk;
+        if (act) {
+            float x, y, z;
+            int32_t c[3];
+            if (load_target_point(raw, soa_y, soa_z, i, stride, has_T, Rt, kp, x, y, z, c))
+                sk = ((uint32_t)(c[km.axis[0]] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint32_t)(c[km.axis[1]] - km.mn[1]) << km.bits[2]) |
+                     (uint32_t)(c[km.axis[2]] - km.mn[2]);
+            elems[i] = make_uint4(sk, __float_as_uint(x), __float_as_uint(y), __float_as_uint(z));
+        }
+        wave_hist_add(h, sk & 255u, act);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+template <int RS_ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist32(const uint4* elems, size_t n, int shift, uint32_t* hist, unsigned nblk) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        const bool act = i < n;
+        const unsigned d = act ? (elems[i].x >> shift) & 255u : 0u;
+        wave_hist_add(h, d, act);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter of whole elements: order inside a tile is (round, wave, lane) = input order
+template <int RS_ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter32(const uint4* elems, size_t n, int shift, const uint32_t* offs, unsigned nblk, uint4* out) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wcnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    running[threadIdx.x] = offs[(size_t)threadIdx.x * nblk + blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
+    for (int r = 0; r < RS_ITEMS; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
+        __syncthreads();
+        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        const bool act = i < n;
+        uint4 e = make_uint4(0, 0, 0, 0);
+        if (act) e = elems[i];
+        const unsigned d = (e.x >> shift) & 255u;
+        unsigned long long m = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot(act && ((d >> b) & 1u));
+            m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (act && rank == 0) wcnt[w][d] = __popcll(m);
+        __syncthreads();
+        if (act) {
+            uint32_t pos = running[d] + rank;
+            for (int j = 0; j < w; ++j) pos += wcnt[j][d];
+            out[pos] = e;
+        }
+        __syncthreads();
+        running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    }
+}
+
+// segment heads of the sorted valid prefix, enumerated in arbitrary order (one returning atomic per block): the order
+// of the voxels of a batch does not matter, the order of the points inside a voxel (input order) is what the sums fix
+__global__ __launch_bounds__(256) void k_seg_heads32(const uint4* elems, uint32_t n_valid, uint32_t* seg_pos, int32_t* plan) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base_s;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool head = i < n_valid && (i == 0 || elems[i].x != elems[i - 1].x);
+    const unsigned long long b = __ballot(head);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base_s = tot ? atomicAdd((uint32_t*)&plan[PL_NSEG], tot) : 0u;
+    }
+    __syncthreads();
+    if (head) {
+        uint32_t pos = base_s + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        for (int j = 0; j < w; ++j) pos += wsum[j];
+        seg_pos[pos] = i;
+    }
+}
+
+// one thread: lanes per segment, big-segment threshold, and whether the batch's voxels are sure to fit the table
+__global__ void k_seg_plan(int32_t* plan, const int32_t* map_counts, uint32_t n_valid, uint64_t cap) {
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
+    const bool wide = nseg && n_valid / nseg >= 24;
+    plan[PL_LANES] = wide ? 64 : 8;
+    plan[PL_BIG] = wide ? 2048 : 512;              // at most 32 / 64 trips of a group's loop
+    plan[PL_ABORT1] = ((uint64_t)map_counts[1] + nseg) * 2 > cap ? 1 : 0;
+}
+
+// end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
+#define SEG_NONE 0xFFFFFFFFu
+__global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t n_valid, const uint32_t* seg_pos, const int32_t* plan, uint32_t* seg_end,
+                                                   uint32_t* big_pos, uint32_t* big_list, uint32_t* big_count) {
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG], big = (uint32_t)plan[PL_BIG];
+    const int lane = threadIdx.x & 63, l = threadIdx.x & 7, gsh = lane & ~7;
+    const uint32_t groups = gridDim.x * 32u;
+    for (uint32_t g0 = (blockIdx.x * 256u + (threadIdx.x & ~63u)) / 8u; g0 < nseg; g0 += groups) {     // g0: first group of this wave
+        const uint32_t g = g0 + (uint32_t)(lane >> 3);
+        const bool act = g < nseg;
+        const uint32_t s = act ? seg_pos[g] : 0u;
+        const uint32_t key = act ? elems[s].x : 0u;
+        uint64_t lo = s, stride = 1;           // elems[lo] holds the key; grows while all eight probes match
+        bool grow = act;
+        while (__any(grow)) {
+            const uint64_t p = lo + (uint64_t)(l + 1) * stride;
+            const bool eq = grow && p < n_valid && elems[p].x == key;
+            const unsigned k = __popc((unsigned)((__ballot(eq) >> gsh) & 0xFFull));    // sorted: matches are a prefix of the probes
+            if (grow) { lo += k * stride; if (k < 8) grow = false; else stride *= 8; }
+        }
+        bool refine = act && stride > 1;       // the end lies in (lo, lo + stride]
+        while (__any(refine)) {
+            if (refine) stride >>= 3;
+            const uint64_t p = lo + (uint64_t)(l + 1) * stride;
+            const bool eq = refine && l < 7 && p < n_valid && elems[p].x == key;
+            const unsigned k = __popc((unsigned)((__ballot(eq) >> gsh) & 0xFFull));
+            if (refine) { lo += k * stride; if (stride == 1) refine = false; }
+        }
+        if (act && l == 0) {
+            const uint32_t e = (uint32_t)lo + 1u;
+            seg_end[g] = e;
+            uint32_t pos = SEG_NONE;
+            if (e - s > big) { pos = atomicAdd(big_count, 1u); big_list[pos] = g; }
+            big_pos[g] = pos;
+        }
+    }
+}
+
+__device__ inline void sortkey32_origin(uint32_t sk, const SortKeyMap& km, double res, int64_t* key, double org[3]) {
+    const int64_t k = sortkey_to_packed((uint64_t)sk, km);
+    int32_t c[3];
+    ndt_unpack(k, c[0], c[1], c[2]);
+    *key = k;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) org[j] = (double)c[j] * res;
+}
+
+__global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, const uint32_t* big_count, const uint4* elems, const uint32_t* seg_pos,
+                                                            const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, double* big_sums) {
+    __shared__ double sm[BIG_THREADS / 64][9];
+    const uint32_t n_big = *big_count;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {       // (uniform over the block)
+    const uint32_t g = big_list[b];
+    const uint32_t s = seg_pos[g], e = seg_end[g];
+    int64_t key;
+    double o[3];
+    sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, o);
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * BIG_THREADS) {       // four elements in flight per lane, added in index order
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * BIG_THREADS;
+            v[u] = i < e ? elems[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * BIG_THREADS >= e) break;
+            const double d0 = (double)__uint_as_float(v[u].y) - o[0], d1 = (double)__uint_as_float(v[u].z) - o[1], d2 = (double)__uint_as_float(v[u].w) - o[2];
+            a[0] += d0; a[1] += d1; a[2] += d2;
+            a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+            a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+        }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o2);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sm[threadIdx.x >> 6][j] = a[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double r = sm[0][threadIdx.x];
+        for (int w = 1; w < BIG_THREADS / 64; ++w) r += sm[w][threadIdx.x];
+        big_sums[(size_t)b * 9 + threadIdx.x] = r;
+    }
+    __syncthreads();
+    }
+}
+
+// lane 0 of a group: ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the
+// table, UpdateMeanAndCov with what the voxel held.  Returns the slot; *fresh_entry / *fresh_voxel tell what was new.
+__device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, int64_t key, int64_t* keys, int32_t* counts, double* mean, double* cov,
+                                                uint64_t mask, bool* fresh_entry, bool* fresh_voxel) {
+    double mu[3] = {a[0] / nb, a[1] / nb, a[2] / nb};
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    if (nb > 1) {   // ComputeMeanAndCov (math_utils.h:55-72): sample covariance over (n-1)
+        const double dn = (double)(nb - 1);
+        cv[0] = (a[3] - a[0] * mu[0]) / dn; cv[1] = (a[4] - a[0] * mu[1]) / dn; cv[2] = (a[5] - a[0] * mu[2]) / dn;
+        cv[3] = (a[6] - a[1] * mu[1]) / dn; cv[4] = (a[7] - a[1] * mu[2]) / dn; cv[5] = (a[8] - a[2] * mu[2]) / dn;
+    }
+    uint64_t slot = ndt_hash_key(key) & mask;
+    bool fresh = false;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
+        if ((int64_t)prev == NDT_KEY_EMPTY) { fresh = true; break; }
+        if ((int64_t)prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    double* mp = mean + slot * 3;
+    double* cp = cov + slot * 6;
+    int32_t ntot = nb;
+    const int32_t had = fresh ? 0 : counts[slot];            // 0 also for a ghost cell that now gets its first points
+    *fresh_entry = fresh;
+    *fresh_voxel = had == 0;
+    if (fresh && slot < 4) keys[mask + 1 + slot] = key;      // mirror entries
+    if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
+        const double hm = (double)had, cn = (double)nb, tot = hm + cn;
+        double nm[3], dh[3], dc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            nm[j] = (hm * mp[j] + cn * mu[j]) / tot;
+            dh[j] = mp[j] - nm[j];
+            dc[j] = mu[j] - nm[j];
+        }
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = r; c < 3; ++c, ++t) cv[t] = (hm * (cp[t] + dh[r] * dh[c]) + cn * (cv[t] + dc[r] * dc[c])) / tot;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu[j] = nm[j];
+        ntot = had + nb;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mp[j] = mu[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cp[j] = cv[j];
+    counts[slot] = ntot;
+    return (uint32_t)slot;
+}
+
+// One group of L lanes (L = 8 or 64, chosen on the device by k_seg_plan) per segment, groups striding over the segments:
+// strided sums in voxel-local float64 coordinates over the segment's contiguous elements, xor tree over the group — the
+// same per-lane order and tree as the 64-bit-key kernel below, so both paths give the same bits — then lane 0 merges.
+__global__ __launch_bounds__(256) void k_segment_merge32(const uint4* __restrict__ elems, const uint32_t* seg_pos, const uint32_t* seg_end, int32_t* plan,
+                                                         SortKeyMap km, MapBuildCfg cfg, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask,
+                                                         uint32_t* seg_slot, const uint32_t* big_pos, const double* big_sums) {
+    if (plan[PL_ABORT1]) return;
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
+    const int L = plan[PL_LANES];
+    const int lane = threadIdx.x & 63, l = lane & (L - 1), gpw = 64 / L;      // groups per wave
+    const uint32_t groups = gridDim.x * 4u * (uint32_t)gpw;
+    uint32_t n_new_vox = 0, n_new_ent = 0;
+    for (uint32_t g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
+        const uint32_t g = g0 + (uint32_t)(lane / L);
+        const bool act = g < nseg;
+        uint32_t s = 0, e = 0, bp = SEG_NONE;
+        int64_t key = 0;
+        double org[3] = {0, 0, 0};
+        if (act) {
+            s = seg_pos[g]; e = seg_end[g]; bp = big_pos[g];
+            sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, org);
+        }
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t e_loop = bp == SEG_NONE ? e : s;          // a big segment was summed by k_big_sums32
+        for (uint32_t i = s + l; i < e_loop; i += L) {
+            const uint4 v = elems[i];
+            const double d0 = (double)__uint_as_float(v.y) - org[0], d1 = (double)__uint_as_float(v.z) - org[1], d2 = (double)__uint_as_float(v.w) - org[2];
+            a[0] += d0; a[1] += d1; a[2] += d2;
+            a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+            a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+        }
+        for (int o = L >> 1; o >= 1; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
+        if (act && l == 0) {
+            if (bp != SEG_NONE) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) a[j] = big_sums[(size_t)bp * 9 + j];
+            }
+            bool fe, fv;
+            seg_slot[g] = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, mask, &fe, &fv);
+            n_new_ent += fe ? 1u : 0u;
+            n_new_vox += fv ? 1u : 0u;
+        }
+    }
+    block_count_add(n_new_vox, &plan[PL_NEW_VOX]);
+    block_count_add(n_new_ent, &plan[PL_NEW_ENT]);
+}
+
+// one voxel of the batch per lane: regularised inverse + payload from the merged statistics
+__global__ __launch_bounds__(256) void k_finalize_segments32(const uint32_t* seg_slot, const int32_t* plan, MapBuildCfg cfg, VoxSlot* slots,
+                                                             const int32_t* counts, const double* mean, const double* cov) {
+    if (plan[PL_ABORT1]) return;
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nseg; g += gridDim.x * blockDim.x) {
+        const size_t slot = seg_slot[g];
+        double mu[3], cv[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu[j] = mean[slot * 3 + j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cv[j] = cov[slot * 6 + j];
+        finalize_slot(&slots[slot], counts[slot], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+    }
+}
+
+// ------------------------------------------------------------------ ghost cells and links of a batch (all paths)
+// where the keys of a batch's voxels come from
+struct SegKeys {
+    const uint4* elems; const uint32_t* seg_pos;           // fast path: sorted 16-byte elements + segment positions
+    const uint64_t* sk64; const uint32_t* seg_start;       // 64-bit-key path: sorted compact keys + segment starts
+    const int64_t* plain;                                   // a plain list of packed keys (map_restore)
+    SortKeyMap km;
+};
+__device__ inline int64_t seg_key(const SegKeys& K, uint32_t g) {
+    if (K.plain) return K.plain[g];
+    if (K.elems) return sortkey_to_packed((uint64_t)K.elems[K.seg_pos[g]].x, K.km);
+    return sortkey_to_packed(K.sk64[K.seg_start[g]], K.km);
+}
+
+// one thread per (voxel of the batch, face direction): neighbours that are not in the table yet
+__global__ __launch_bounds__(256) void k_ghost_count(SegKeys K, const int32_t* d_nseg, const int64_t* keys, uint64_t mask, int32_t* plan) {
+    if (plan[PL_ABORT1]) return;
+    const uint32_t nseg = (uint32_t)*d_nseg;
+    uint32_t missing = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)nseg * 8; t += (uint64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(t & 7);
+        if (d >= 6) continue;
+        int64_t nk;
+        if (neighbour_key(seg_key(K, (uint32_t)(t >> 3)), d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++missing;
+    }
+    block_count_add(missing, &plan[PL_MISSING]);
+}
+// one thread: the voxel stage's counts join the map's counters; do the ghost cells fit?
+__global__ void k_ghost_plan(int32_t* plan, int32_t* map_counts, const int32_t* new_vox, const int32_t* new_ent, uint64_t cap) {
+    map_counts[0] += *new_vox;
+    map_counts[1] += *new_ent;
+    plan[PL_ABORT2] = (!plan[PL_ABORT1] && ((uint64_t)map_counts[1] + (uint64_t)plan[PL_MISSING]) * 2 > cap) ? 1 : 0;
+}
+// one thread per (voxel of the batch, face direction): find-or-insert the neighbour cell and link the two entries both
+// ways.  Every voxel's six neighbours are in the table from the moment it gets its first points, so an entry that is
+// created here (a ghost) can only touch voxels of this batch, whose own threads link it: no table-wide pass is needed.
+// Links between two ghost cells are never read (a ghost contributes nothing to a residual) and stay unset.
+__global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_nseg, int64_t* keys, VoxSlot* slots, uint64_t mask, int32_t* plan) {
+    if (plan[PL_ABORT1] || plan[PL_ABORT2]) return;
+    const uint32_t nseg = (uint32_t)*d_nseg;
+    uint32_t inserted = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)nseg * 8; t += (uint64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(t & 7);
+        if (d >= 6) continue;
+        const int64_t key = seg_key(K, (uint32_t)(t >> 3));
+        const uint32_t own = table_find(keys, mask, key);
+        int64_t nk;
+        if (own == NDT_LINK_NONE || !neighbour_key(key, d, &nk)) continue;
+        uint64_t slot = ndt_hash_key(nk) & mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)nk);
+            if ((int64_t)prev == NDT_KEY_EMPTY) { ++inserted; if (slot < 4) keys[mask + 1 + slot] = nk; break; }   // the slot is zeroed: a ghost
+            if ((int64_t)prev == nk) break;
+            slot = (slot + 1) & mask;
+        }
+        slots[own].link[d] = (uint32_t)slot;
+        slots[slot].link[d ^ 1] = own;
+    }
+    block_count_add(inserted, &plan[PL_NEW_GHOST]);
+}
+__global__ void k_ghost_done(int32_t* plan, int32_t* map_counts) { map_counts[1] += plan[PL_NEW_GHOST]; }
+__global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
+
+#define STAGE_BLOCKS 1024      // grid of the segment-striding kernels
+
+struct PlanWords { int32_t nseg, lanes, big, abort1, abort2, missing, new_vox, new_ent, new_ghost, n_vox, n_entries; };
+static int read_plan(const VoxelMap& m, const MapWork& w, PlanWords* p, hipStream_t s, std::string& err) {
+    int32_t a[8], c[2], ns;
+    HIP_TRY(hipMemcpyAsync(a, w.misc.as<int32_t>() + PL_LANES, sizeof a, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&ns, w.misc.as<int32_t>() + PL_NSEG, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c, m.d_n_vox, sizeof c, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    m.n_vox += sums[0];
-    m.n_entries += sums[1];
-    if (sums[2]) {
-        rc = map_reserve(m, (size_t)m.n_entries + sums[2], s, err);
-        if (rc != NDT_OK) return rc;
-        k_ghost_insert<<<nbseg, 256, 0, s>>>(sorted_keys, segs, plain, nseg, km, m.keys, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>());
-        sum_flags(w.flags.as<uint32_t>(), d_sums + 3);
-    }
-    k_link_all<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.cap);
-    HIP_TRY(hipGetLastError());
-    if (sums[2]) {
-        HIP_TRY(hipMemcpyAsync(sums + 3, d_sums + 3, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        m.n_entries += sums[3];
-    }
+    *p = PlanWords{ns, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], c[0], c[1]};
     return NDT_OK;
 }
 
-// Stage 1 of every cloud ingest: (optional transform,) cell of every point, LSD radix sort of (cell, index),
-// segments (= cells); the per-cell sums read the points through the sorted index (sorted_vals), so no sorted copy is made.  pts: AoS records in host or device
-// memory, or (stride == 0) three device SoA arrays passed through pts / soa_y / soa_z.
-int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
-                        const double* R, const double* t, bool zyx_order, bool host_nseg, hipStream_t s, SortedCells* out, std::string& err) {
-    *out = SortedCells();
-    if (n == 0) return NDT_OK;
-    if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
+// Ghost cells + links for the batch whose voxels are already merged (their counts in *new_vox / *new_ent, device words), then
+// the one read-back of the call.  Grows the table and re-runs when the device found that the ghost cells might not fit.
+static int ghost_stage(VoxelMap& m, MapWork& w, SegKeys K, const int32_t* d_nseg, uint32_t nseg_ub, const int32_t* d_new_vox, const int32_t* d_new_ent,
+                       PlanWords* pw, hipStream_t s, std::string& err) {
+    int32_t* plan = w.misc.as<int32_t>();
+    const unsigned nb = (unsigned)std::min<uint64_t>(STAGE_BLOCKS, ((uint64_t)nseg_ub * 8 + 255) / 256);
+    k_ghost_count<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, (uint64_t)(m.cap - 1), plan);
+    k_ghost_plan<<<1, 1, 0, s>>>(plan, m.d_n_vox, d_new_vox, d_new_ent, (uint64_t)m.cap);
+    k_ghost_link<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, m.slots, (uint64_t)(m.cap - 1), plan);
+    k_ghost_done<<<1, 1, 0, s>>>(plan, m.d_n_vox);
+    HIP_TRY(hipGetLastError());
+    int rc = read_plan(m, w, pw, s, err);
+    if (rc != NDT_OK) return rc;
+    if (!pw->abort1 && pw->abort2) {      // the voxels are in, their ghosts were not attempted: make room (links are rebuilt), then link
+        m.n_vox = pw->n_vox; m.n_entries = pw->n_entries;
+        rc = map_reserve(m, (size_t)pw->n_entries + (size_t)pw->missing, s, err);
+        if (rc != NDT_OK) return rc;
+        HIP_TRY(hipMemsetAsync(plan + PL_ABORT2, 0, 4, s));
+        k_ghost_link<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, m.slots, (uint64_t)(m.cap - 1), plan);
+        k_ghost_done<<<1, 1, 0, s>>>(plan, m.d_n_vox);
+        HIP_TRY(hipGetLastError());
+        rc = read_plan(m, w, pw, s, err);
+        if (rc != NDT_OK) return rc;
+    }
+    if (!pw->abort1) { m.n_vox = pw->n_vox; m.n_entries = pw->n_entries; }
+    return NDT_OK;
+}
+
+// Stage 1 of every cloud ingest: staging (host records are copied; device records and SoA arrays are read in place),
+// bounding box of the cells, sort-key layout.  The one read-back every ingest needs: the radix pass count depends on it.
+struct IngestBox { const unsigned char* d_in; double* dRt; size_t n_valid; int32_t misc[8]; SortKeyMap km; int total_bits; uint64_t bbox_cells; };
+static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride, const double* R,
+                       const double* t, bool zyx_order, bool write_keys, hipStream_t s, IngestBox* out, std::string& err) {
     const unsigned char* d_in = (const unsigned char*)pts;
     if (stride) {
-        // records already in device memory are read in place (k_target_keys is their only reader and runs before this
-        // function's first synchronisation, so the caller's buffer is free again on return either way)
+        // records already in device memory are read in place (the key kernels are their only readers and have run when
+        // the call returns, so the caller's buffer is free again on return either way)
         hipPointerAttribute_t at;
         int dev = -1;
         (void)hipGetDevice(&dev);
@@ -792,10 +1197,8 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
             d_in = (const unsigned char*)w.raw.p;
         }
     }
-    HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
-    HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.keys_b.ensure(n * 8));
-    HIP_TRY(w.vals_a.ensure(n * 4)); HIP_TRY(w.vals_b.ensure(n * 4));
     HIP_TRY(w.misc.ensure(256));
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_LANES, 0, 32, s));       // the plan words of this call start at zero
     double* dRt = (double*)((char*)w.misc.p + 64);
     if (R) {
         double Rt[12];
@@ -806,25 +1209,62 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     const unsigned nb_tk = std::min<unsigned>(nb256, TK_MAX_BLOCKS);
     HIP_TRY(w.block_rows.ensure((size_t)TK_MAX_BLOCKS * 8 * 4));
-    k_target_keys<<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, w.tx.as<float>(), w.ty.as<float>(),
-                                        w.tz.as<float>(), w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+    if (write_keys) {
+        HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
+        HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4));
+        k_target_keys<true><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
+                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+    } else {
+        k_target_keys<false><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                   w.block_rows.as<int32_t>());
+    }
     k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    int32_t misc[8];
-    HIP_TRY(hipMemcpyAsync(misc, w.misc.p, sizeof misc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out->misc, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const size_t n_valid = (size_t)misc[6];
-    if (n_valid == 0) return NDT_OK;
-
-    SortKeyMap km;
-    int total_bits = 0;
+    out->d_in = d_in; out->dRt = dRt;
+    out->n_valid = (size_t)out->misc[6];
+    out->total_bits = 0; out->bbox_cells = 1;
     for (int j = 0; j < 3; ++j) {
         const int ax = zyx_order ? 2 - j : j;
-        km.axis[j] = ax;
-        km.mn[j] = misc[ax];
-        km.bits[j] = bits_for((int64_t)misc[3 + ax] - misc[ax] + 1);
-        total_bits += km.bits[j];
+        out->km.axis[j] = ax;
+        out->km.mn[j] = out->misc[ax];
+        out->km.bits[j] = out->n_valid ? bits_for((int64_t)out->misc[3 + ax] - out->misc[ax] + 1) : 0;
+        out->total_bits += out->km.bits[j];
+        if (out->n_valid) out->bbox_cells *= (uint64_t)((int64_t)out->misc[3 + j] - out->misc[j] + 1);
     }
+    return NDT_OK;
+}
+
+// LSD radix sort of (compact 64-bit key, point index) + ordered segments: the path for bounding boxes of more than 2^32
+// cells and for the VoxelGrid downsample (whose output order is the cells' order).  The per-cell sums read the points through
+// the sorted index.  pts: AoS records in host or device memory, or (stride == 0) three device SoA arrays passed through
+// pts / soa_y / soa_z.
+int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
+                        const double* R, const double* t, bool zyx_order, bool host_nseg, hipStream_t s, SortedCells* out, std::string& err,
+                        const IngestBox* have_box = nullptr) {
+    *out = SortedCells();
+    if (n == 0) return NDT_OK;
+    if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
+    IngestBox box;
+    if (have_box) {         // the fast path measured the box and found the keys too wide: make the 64-bit keys now
+        box = *have_box;
+        const unsigned nb_tk = std::min<unsigned>((unsigned)((n + 255) / 256), TK_MAX_BLOCKS);
+        HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
+        HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4));
+        k_target_keys<true><<<nb_tk, 256, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
+                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+        HIP_TRY(hipGetLastError());
+    } else {
+        int rc = ingest_bbox(w, kp, pts, soa_y, soa_z, n, stride, R, t, zyx_order, true, s, &box, err);
+        if (rc != NDT_OK) return rc;
+    }
+    const size_t n_valid = box.n_valid;
+    if (n_valid == 0) return NDT_OK;
+    const SortKeyMap km = box.km;
+    const int total_bits = box.total_bits;
+    const unsigned nb256 = (unsigned)((n + 255) / 256);
+    HIP_TRY(w.keys_b.ensure(n * 8)); HIP_TRY(w.vals_b.ensure(n * 4));
     // Points that were dropped (non-finite / out of key range) get a sort key of their own, 1 << total_bits, so that they
     // can never tie with the all-ones key of the bounding box's max corner (a 128 x 128 x 4 box has exactly 16 key bits);
     // the extra bit is sorted only when such points exist.
@@ -869,16 +1309,15 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
     k_seg_starts<<<nbv, 256, 0, s>>>(w.flags.as<uint32_t>(), w.segid.as<uint32_t>(), n_valid, w.seg_start.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     out->n_valid = n_valid; out->nseg = nseg; out->d_nseg = d_nseg; out->km = km; out->passes = P; out->sorted_keys = ka; out->sorted_vals = va;
-    out->bbox_cells = 1;
-    for (int j = 0; j < 3; ++j) out->bbox_cells *= (uint64_t)((int64_t)misc[3 + j] - misc[j] + 1);
+    out->bbox_cells = box.bbox_cells;
     return NDT_OK;
 }
 
-int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
-                     size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
-    if (passes) *passes = 0;
+// 64-bit-key path of a map merge (bounding boxes of more than 2^32 cells): ordered segments, sums through the sorted index
+static int map_merge_wide(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride,
+                          const double* R, const double* t, const IngestBox& box, hipStream_t s, int* passes, std::string& err) {
     SortedCells sc;
-    int rc = sort_points_by_cell(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, true, s, &sc, err);
+    int rc = sort_points_by_cell(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, true, s, &sc, err, &box);
     if (rc != NDT_OK) return rc;
     if (passes) *passes = sc.passes;
     if (sc.nseg == 0) return map_reserve(m, 1, s, err);
@@ -907,8 +1346,94 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
                                                m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(), w.flags2.as<uint32_t>(), seg_slot, w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
     }
     k_finalize_segments<<<(nseg + 255) / 256, 256, 0, s>>>(seg_slot, nseg, cfg, m.slots, m.counts, m.mean, m.cov);
+    // sums of the per-voxel flags (new voxels, new table entries) stay on the device: misc[8], misc[9]
+    int32_t* plan = w.misc.as<int32_t>();
+    const size_t nbf = ((size_t)nseg + SCAN_TILE - 1) / SCAN_TILE;
+    HIP_TRY(w.scan_tmp.ensure((nbf + 2) * 4));
+    k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(w.flags.as<uint32_t>(), nseg, w.scan_tmp.as<uint32_t>());
+    k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, (uint32_t*)(plan + 8));
+    k_scan_reduce<<<(unsigned)nbf, SCAN_THREADS, 0, s>>>(w.flags2.as<uint32_t>(), nseg, w.scan_tmp.as<uint32_t>());
+    k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, (uint32_t*)(plan + 9));
     HIP_TRY(hipGetLastError());
-    return finish_entries(m, w, sc.sorted_keys, segs, nullptr, nseg, sc.km, s, err);
+    SegKeys K{};
+    K.sk64 = sc.sorted_keys; K.seg_start = segs; K.km = sc.km;
+    PlanWords pw;
+    return ghost_stage(m, w, K, plan + PL_NSEG, nseg, plan + 8, plan + 9, &pw, s, err);
+}
+
+// Map build / keyframe merge.  One read-back for the bounding box, one at the end for everything the device decided.
+int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
+                     size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
+    if (passes) *passes = 0;
+    if (n == 0) return map_reserve(m, 1, s, err);
+    if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
+    IngestBox box;
+    int rc = ingest_bbox(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, false, s, &box, err);
+    if (rc != NDT_OK) return rc;
+    if (box.n_valid == 0) return map_reserve(m, 1, s, err);
+    const bool has_invalid = box.n_valid < n;
+    if (box.total_bits + (has_invalid ? 1 : 0) > 32) return map_merge_wide(m, w, cfg, pts, soa_y, soa_z, n, stride, R, t, box, s, passes, err);
+
+    // ---- 16-byte elements {compact key, x, y, z} + the first digit's histograms
+    const size_t n_valid = box.n_valid;
+    const int P = std::max(1, (box.total_bits + (has_invalid ? 1 : 0) + 7) / 8);
+    if (passes) *passes = P;
+    // tiles: 4096 elements for big clouds; for a LiDAR scan 4096 too, so that its 256 x blocks histogram fits the one-block scan
+    const size_t rs_tile = (size_t)RS_THREADS * RS_ITEMS_BIG;
+    const unsigned nblk = (unsigned)((n + rs_tile - 1) / rs_tile);
+    const size_t nh = (size_t)256 * nblk;
+    HIP_TRY(w.keys_a.ensure(n * 16)); HIP_TRY(w.keys_b.ensure(n * 16));
+    HIP_TRY(w.hist.ensure(nh * 4));
+    HIP_TRY(w.scan_tmp.ensure(((nh + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
+    uint4* ea = w.keys_a.as<uint4>(); uint4* eb = w.keys_b.as<uint4>();
+    const uint32_t invalid_sk = has_invalid ? (uint32_t)(1ull << box.total_bits) : 0xFFFFFFFFu;
+    k_make_elems32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, cfg.kp, box.km, invalid_sk, ea,
+                                                             w.hist.as<uint32_t>(), nblk);
+    for (int p = 0; p < P; ++p) {
+        if (p) k_radix_hist32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ea, n, 8 * p, w.hist.as<uint32_t>(), nblk);
+        exclusive_scan_u32(w.hist.as<uint32_t>(), w.hist.as<uint32_t>(), nh, w.scan_tmp.as<uint32_t>(), nullptr, s);
+        k_radix_scatter32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ea, n, 8 * p, w.hist.as<uint32_t>(), nblk, eb);
+        std::swap(ea, eb);
+    }
+    HIP_TRY(hipGetLastError());
+
+    // ---- segments (unordered), plan, ends, sums, merge, payloads
+    const size_t nseg_ub = (size_t)std::min<uint64_t>(n_valid, box.bbox_cells);
+    HIP_TRY(w.seg_start.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.flags.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.segid.ensure(nseg_ub * 4 + 16));
+    HIP_TRY(w.big_pos.ensure(nseg_ub * 4 + 16));
+    const size_t big_ub = n_valid / 512 + 1;                    // no more segments than this can be longer than the smaller threshold
+    HIP_TRY(w.big_list.ensure(big_ub * 4 + 16)); HIP_TRY(w.big_sums.ensure(big_ub * 9 * 8 + 16));
+    uint32_t* seg_pos = w.seg_start.as<uint32_t>(); uint32_t* seg_end = w.flags.as<uint32_t>(); uint32_t* seg_slot = w.segid.as<uint32_t>();
+    int32_t* plan = w.misc.as<int32_t>();
+    uint32_t* big_count = (uint32_t*)(plan + PL_BIGCOUNT);
+    if (!m.cap) { rc = map_reserve(m, 1, s, err); if (rc != NDT_OK) return rc; }
+    const unsigned nbv = (unsigned)((n_valid + 255) / 256);
+    const unsigned nb_seg = (unsigned)std::min<uint64_t>(STAGE_BLOCKS, (nseg_ub * 8 + 255) / 256);
+    SegKeys K{};
+    K.elems = ea; K.seg_pos = seg_pos; K.km = box.km;
+    k_seg_heads32<<<nbv, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] was zeroed by k_bbox_reduce
+    k_seg_plan<<<1, 1, 0, s>>>(plan, m.d_n_vox, (uint32_t)n_valid, (uint64_t)m.cap);
+    k_seg_ends32<<<nb_seg, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
+    k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, ea, seg_pos, seg_end, box.km, cfg,
+                                                                                 w.big_sums.as<double>());
+    HIP_TRY(hipGetLastError());
+    PlanWords pw;
+    for (int attempt = 0;; ++attempt) {
+        k_segment_merge32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, m.keys, m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), seg_slot,
+                                                       w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
+        k_finalize_segments32<<<nb_seg, 256, 0, s>>>(seg_slot, plan, cfg, m.slots, m.counts, m.mean, m.cov);
+        HIP_TRY(hipGetLastError());
+        rc = ghost_stage(m, w, K, plan + PL_NSEG, (uint32_t)nseg_ub, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
+        if (rc != NDT_OK) return rc;
+        if (!pw.abort1) break;
+        if (attempt >= 2) { err = "voxel table could not be sized for the batch"; return NDT_ERR_HIP; }
+        // the device found that the batch's voxels might not fit (nothing was inserted): room for them and, at the usual
+        // ratio, their ghost cells; then the insert stages run again on the sorted data that is still in place
+        rc = map_reserve(m, (size_t)m.n_entries + (size_t)pw.nseg + (size_t)pw.nseg * 3 / 2, s, err);
+        if (rc != NDT_OK) return rc;
+        HIP_TRY(hipMemsetAsync(plan + PL_ABORT1, 0, 24, s));               // abort flags, missing, new_vox, new_ent, new_ghost
+    }
+    return NDT_OK;
 }
 
 // Scan pre-processing: pcl::transformPointCloud + pcl::VoxelGrid(leaf) of process.cc:62-73 —
@@ -1069,7 +1594,7 @@ int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>
 int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
                 size_t n, hipStream_t s, std::string& err) {
     if (n >= (1ull << 31)) { err = "more than 2^31 voxels"; return NDT_ERR_INVALID_ARG; }
-    int rc = map_reserve(m, n ? n : 1, s, err);
+    int rc = map_reserve(m, n ? n * 5 / 2 : 1, s, err);      // voxels + their ghost cells at the usual ratio (the ghost stage grows the table if not)
     if (rc != NDT_OK || n == 0) return rc;
     HIP_TRY(w.misc.ensure(256));
     HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4)); HIP_TRY(w.keys_b.ensure(n * 24)); HIP_TRY(w.raw.ensure(n * 48));
@@ -1082,6 +1607,15 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
                                                          cfg, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(),
                                                          w.flags2.as<uint32_t>());
     HIP_TRY(hipGetLastError());
-    SortKeyMap km{};
-    return finish_entries(m, w, nullptr, nullptr, w.keys_a.as<int64_t>(), (uint32_t)n, km, s, err);
+    // every key is new (the blob was validated: distinct keys into a cleared map): n voxels, n table entries
+    int32_t* plan = w.misc.as<int32_t>();
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_LANES, 0, 32, s));
+    k_set_word<<<1, 1, 0, s>>>(plan + PL_NSEG, (int32_t)n);
+    k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_VOX, (int32_t)n);
+    k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_ENT, (int32_t)n);
+    HIP_TRY(hipGetLastError());
+    SegKeys K{};
+    K.plain = w.keys_a.as<int64_t>();
+    PlanWords pw;
+    return ghost_stage(m, w, K, plan + PL_NSEG, (uint32_t)n, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
 }
