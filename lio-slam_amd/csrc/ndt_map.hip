@@ -169,6 +169,7 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
     }
     if (threadIdx.x == 7) misc[7] = 0;
     if (threadIdx.x == 12) misc[12] = 0;
+    if (threadIdx.x == 13) misc[13] = 0;
 }
 
 // pass 2: packed key -> compact sort key (bbox-relative, bit-packed); invalid points sort last
@@ -699,7 +700,6 @@ static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::str
                                                                 nm.cov, ncap - 1);
         k_link_all<<<(unsigned)((ncap + 255) / 256), 256, 0, s>>>(nm.keys, nm.slots, ncap);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(nm.d_n_vox, m.d_n_vox, 8, hipMemcpyDeviceToDevice, s));     // the device-side counters move with the map
         nm.n_vox = m.n_vox; nm.n_entries = m.n_entries;
         HIP_TRY(hipStreamSynchronize(s));
         map_free(m);
@@ -713,15 +713,16 @@ static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; 
 // ------------------------------------------------------------------ plan / counter words
 // Everything the stages after the bounding box decide is decided on the DEVICE and read back once, at the end of the call:
 // w.misc (int32 words): [0..5] bbox, [6] n_valid, [7] nseg, [8..11] flag sums (64-bit-key path), [12] big segments,
-// [16..39] keyframe transform, [40..47] the words below.  VoxelMap::d_n_vox: [0] voxels with points, [1] table entries.
+// [13] one-sweep sort error, [16..39] keyframe transform, [40..47] the words below.  The map's own counters (voxels,
+// table entries) are the host's (VoxelMap::n_vox / n_entries, exact after every call's read-back) and reach the kernels
+// as arguments.
 #define PL_NSEG 7
 #define PL_BIGCOUNT 12
-#define PL_LANES 40      // lanes per segment in the sums (8 | 64)
-#define PL_BIG 41        // segments longer than this are summed by a whole block
+#define PL_SORT_ERR 13   // a one-sweep pass gave up waiting for a predecessor tile (never seen; the host then sorts with the three-kernel passes)
 #define PL_ABORT1 42     // the batch's voxels may not fit the table: the insert stages did nothing, the host grows the table and re-runs them
 #define PL_ABORT2 43     // the ghost cells may not fit: the ghost stage did nothing, the host grows the table and re-runs it
-#define PL_MISSING 44    // neighbours of the batch's voxels that are not in the table (upper bound of the ghosts to add)
-#define PL_NEW_VOX 45    // voxels that got their first points
+#define PL_MISSING 44    // neighbours of the batch's new voxels that are not in the table (upper bound of the ghosts to add)
+#define PL_NEW_VOX 45    // voxels that got their first points (= length of the fresh list)
 #define PL_NEW_ENT 46    // table entries created for voxels
 #define PL_NEW_GHOST 47  // table entries created for ghost cells
 
@@ -740,30 +741,42 @@ __device__ __forceinline__ void block_count_add(uint32_t v, int32_t* dst) {
 // ------------------------------------------------------------------ fast path: compact keys of <= 32 bits
 // One 16-byte element {sort key, x, y, z} per point travels through the radix passes (one dwordx4 per lane), so the
 // per-voxel sums afterwards read their points as a contiguous stream instead of gathering them through a sorted index.
+// Each pass is ONE kernel (histogram, chained scan over the tiles with look-back, scatter), after the digit totals of
+// all passes were counted while the elements were made.
 
-// LDS histogram add with same-digit lanes of a wave combined first (a LiDAR ring's consecutive points share their digit:
-// plain LDS atomics would serialise 64 ways)
-__device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act) {
+// lanes of the wave that hold the same 8-bit digit as this lane (for active lanes)
+__device__ __forceinline__ unsigned long long same_digit_lanes(unsigned d, bool act) {
     unsigned long long m = __ballot(act);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const unsigned long long bal = __ballot(act && ((d >> b) & 1u));
         m &= ((d >> b) & 1u) ? bal : ~bal;
     }
+    return m;
+}
+// LDS histogram add with same-digit lanes of a wave combined first (a LiDAR ring's consecutive points share their digit:
+// plain LDS atomics would serialise 64 ways)
+__device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act) {
+    const unsigned long long m = same_digit_lanes(d, act);
     const int lane = threadIdx.x & 63;
     if (act && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(m));
 }
 
-template <int RS_ITEMS>
+#define OS_ITEMS 16
+#define OS_TILE (RS_THREADS * OS_ITEMS)        // 4096 elements per tile
+#define OS_MAX_PASSES 4
+#define ME_MAX_BLOCKS 512                       // blocks of k_make_elems32: bounds the same-address adds into the digit totals
+
+// elements + digit totals of every pass (ghist[p][256]); blocks stride over the tiles
 __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T,
-                                                             const double* Rt, KeyParams kp, SortKeyMap km, uint32_t invalid_sk, uint4* elems, uint32_t* hist,
-                                                             unsigned nblk) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+                                                             const double* Rt, KeyParams kp, SortKeyMap km, uint32_t invalid_sk, int passes, uint4* elems,
+                                                             uint32_t* ghist) {
+    __shared__ uint32_t h[OS_MAX_PASSES][256];
+#pragma unroll
+    for (int p = 0; p < OS_MAX_PASSES; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * (RS_THREADS * RS_ITEMS);
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * RS_THREADS; base < n; base += (size_t)gridDim.x * RS_THREADS) {      // (uniform over the block)
+        const size_t i = base + threadIdx.x;
         const bool act = i < n;
         uint32_t sk = invalid_sk;
         if (act) {
@@ -774,12 +787,93 @@ __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char
                      (uint32_t)(c[km.axis[2]] - km.mn[2]);
             elems[i] = make_uint4(sk, __float_as_uint(x), __float_as_uint(y), __float_as_uint(z));
         }
-        wave_hist_add(h, sk & 255u, act);
+        for (int p = 0; p < passes; ++p) wave_hist_add(h[p], (sk >> (8 * p)) & 255u, act);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    for (int p = 0; p < passes; ++p)
+        if (h[p][threadIdx.x]) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
 }
 
+// One radix pass in one kernel.  A block takes the next tile (ticket), counts its digits, publishes the counts, adds up
+// the counts of the tiles before it by looking back (a tile's word per digit is {flag, count}: its own count first, the
+// inclusive prefix once known; 8-byte agent-scope atomic stores and loads, every word self-contained), then scatters its
+// elements — kept in registers — stably: (round, wave, lane) = input order.  Tiles are numbered in ticket order, so
+// every tile a block waits for has been started; the wait is bounded all the same and raises *err when it runs out.
+#define OS_AGG (1ull << 62)
+#define OS_PRE (2ull << 62)
+#define OS_VAL ((1ull << 62) - 1ull)
+#define OS_SPIN_LIMIT (1 << 22)
+__global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
+                                                           const uint32_t* __restrict__ ghist, unsigned long long* status, uint32_t* ticket, int32_t* err) {
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wcnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const size_t base = (size_t)tile * OS_TILE;
+    uint4 e[OS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        e[r] = i < n ? in[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+        const bool act = base + (size_t)r * RS_THREADS + threadIdx.x < n;
+        wave_hist_add(h, (e[r].x >> shift) & 255u, act);
+    }
+    __syncthreads();
+    // this thread owns digit threadIdx.x: global base of the digit + what the earlier tiles hold of it
+    const uint32_t excl = block_exclusive_scan_256(ghist[threadIdx.x], nullptr);
+    const unsigned long long cnt = h[threadIdx.x];
+    unsigned long long* mine = status + (size_t)tile * 256 + threadIdx.x;
+    unsigned long long before = 0;
+    if (tile == 0) {
+        __hip_atomic_store(mine, OS_PRE | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(mine, OS_AGG | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        for (uint32_t t = tile; t-- > 0;) {
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(status + (size_t)t * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >> 62) break;
+                if (++spins > OS_SPIN_LIMIT) { *err = 1; v = OS_PRE; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            before += v & OS_VAL;
+            if ((v >> 62) == 2ull) break;
+        }
+        __hip_atomic_store(mine, OS_PRE | (before + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    running[threadIdx.x] = excl + (uint32_t)before;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
+        __syncthreads();
+        const bool act = base + (size_t)r * RS_THREADS + threadIdx.x < n;
+        const unsigned d = (e[r].x >> shift) & 255u;
+        const unsigned long long m = same_digit_lanes(d, act);
+        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (act && rank == 0) wcnt[w][d] = __popcll(m);
+        __syncthreads();
+        if (act) {
+            uint32_t pos = running[d] + rank;
+            for (int j = 0; j < w; ++j) pos += wcnt[j][d];
+            if (pos < n) out[pos] = e[r];        // (always, unless a wait ran out)
+        }
+        __syncthreads();
+        running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    }
+}
+
+// the three-kernel form of a pass (histograms per tile, exclusive scan, scatter): the fallback of k_onesweep32
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist32(const uint4* elems, size_t n, int shift, uint32_t* hist, unsigned nblk) {
     __shared__ uint32_t h[256];
@@ -795,8 +889,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist32(const uint4* elems,
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
-
-// stable scatter of whole elements: order inside a tile is (round, wave, lane) = input order
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter32(const uint4* elems, size_t n, int shift, const uint32_t* offs, unsigned nblk, uint4* out) {
     __shared__ uint32_t running[256];
@@ -813,12 +905,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter32(const uint4* ele
         uint4 e = make_uint4(0, 0, 0, 0);
         if (act) e = elems[i];
         const unsigned d = (e.x >> shift) & 255u;
-        unsigned long long m = __ballot(act);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long bal = __ballot(act && ((d >> b) & 1u));
-            m &= ((d >> b) & 1u) ? bal : ~bal;
-        }
+        const unsigned long long m = same_digit_lanes(d, act);
         const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
         if (act && rank == 0) wcnt[w][d] = __popcll(m);
         __syncthreads();
@@ -832,55 +919,64 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter32(const uint4* ele
     }
 }
 
-// segment heads of the sorted valid prefix, enumerated in arbitrary order (one returning atomic per block): the order
-// of the voxels of a batch does not matter, the order of the points inside a voxel (input order) is what the sums fix
-__global__ __launch_bounds__(256) void k_seg_heads32(const uint4* elems, uint32_t n_valid, uint32_t* seg_pos, int32_t* plan) {
-    __shared__ uint32_t wsum[4];
+// segment heads of the sorted valid prefix, enumerated in arbitrary order (one returning atomic per 4096 elements): the
+// order of the voxels of a batch does not matter, the order of the points inside a voxel (input order) is what the sums fix
+#define SH_THREADS 1024
+#define SH_ITEMS 4
+__global__ __launch_bounds__(SH_THREADS) void k_seg_heads32(const uint4* elems, uint32_t n_valid, uint32_t* seg_pos, int32_t* plan) {
+    __shared__ uint32_t wtot[SH_THREADS / 64];
     __shared__ uint32_t base_s;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool head = i < n_valid && (i == 0 || elems[i].x != elems[i - 1].x);
-    const unsigned long long b = __ballot(head);
-    if (lane == 0) wsum[w] = (uint32_t)__popcll(b);
+    const uint32_t* keys = (const uint32_t*)elems;          // key of element i = word 4 i
+    const uint32_t base = blockIdx.x * (SH_THREADS * SH_ITEMS);
+    unsigned long long b[SH_ITEMS];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < SH_ITEMS; ++j) {
+        const uint32_t i = base + j * SH_THREADS + threadIdx.x;
+        const bool head = i < n_valid && (i == 0 || keys[4 * (size_t)i] != keys[4 * (size_t)i - 4]);
+        b[j] = __ballot(head);
+        tot += (uint32_t)__popcll(b[j]);
+    }
+    if (lane == 0) wtot[w] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        base_s = tot ? atomicAdd((uint32_t*)&plan[PL_NSEG], tot) : 0u;
+        uint32_t t = 0;
+        for (int j = 0; j < SH_THREADS / 64; ++j) t += wtot[j];
+        base_s = t ? atomicAdd((uint32_t*)&plan[PL_NSEG], t) : 0u;
     }
     __syncthreads();
-    if (head) {
-        uint32_t pos = base_s + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        for (int j = 0; j < w; ++j) pos += wsum[j];
-        seg_pos[pos] = i;
+    uint32_t pos = base_s;
+    for (int j = 0; j < w; ++j) pos += wtot[j];
+#pragma unroll
+    for (int j = 0; j < SH_ITEMS; ++j) {
+        if ((b[j] >> lane) & 1ull) seg_pos[pos + (uint32_t)__popcll(b[j] & ((1ull << lane) - 1ull))] = base + j * SH_THREADS + threadIdx.x;
+        pos += (uint32_t)__popcll(b[j]);
     }
 }
 
-// one thread: lanes per segment, big-segment threshold, and whether the batch's voxels are sure to fit the table
-__global__ void k_seg_plan(int32_t* plan, const int32_t* map_counts, uint32_t n_valid, uint64_t cap) {
-    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
-    const bool wide = nseg && n_valid / nseg >= 24;
-    plan[PL_LANES] = wide ? 64 : 8;
-    plan[PL_BIG] = wide ? 2048 : 512;              // at most 32 / 64 trips of a group's loop
-    plan[PL_ABORT1] = ((uint64_t)map_counts[1] + nseg) * 2 > cap ? 1 : 0;
-}
+// what the segment kernels derive from the segment count, each for itself (no planning kernel in between)
+__device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 24; }   // 64 lanes per segment, else 8
+__device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? 2048u : 512u; }   // <= 32 / 64 trips
 
 // end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
 #define SEG_NONE 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t n_valid, const uint32_t* seg_pos, const int32_t* plan, uint32_t* seg_end,
                                                    uint32_t* big_pos, uint32_t* big_list, uint32_t* big_count) {
-    const uint32_t nseg = (uint32_t)plan[PL_NSEG], big = (uint32_t)plan[PL_BIG];
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG], big = seg_big(nseg, n_valid);
+    const uint32_t* keys = (const uint32_t*)elems;
     const int lane = threadIdx.x & 63, l = threadIdx.x & 7, gsh = lane & ~7;
     const uint32_t groups = gridDim.x * 32u;
     for (uint32_t g0 = (blockIdx.x * 256u + (threadIdx.x & ~63u)) / 8u; g0 < nseg; g0 += groups) {     // g0: first group of this wave
         const uint32_t g = g0 + (uint32_t)(lane >> 3);
         const bool act = g < nseg;
         const uint32_t s = act ? seg_pos[g] : 0u;
-        const uint32_t key = act ? elems[s].x : 0u;
+        const uint32_t key = act ? keys[4 * (size_t)s] : 0u;
         uint64_t lo = s, stride = 1;           // elems[lo] holds the key; grows while all eight probes match
         bool grow = act;
         while (__any(grow)) {
             const uint64_t p = lo + (uint64_t)(l + 1) * stride;
-            const bool eq = grow && p < n_valid && elems[p].x == key;
+            const bool eq = grow && p < n_valid && keys[4 * p] == key;
             const unsigned k = __popc((unsigned)((__ballot(eq) >> gsh) & 0xFFull));    // sorted: matches are a prefix of the probes
             if (grow) { lo += k * stride; if (k < 8) grow = false; else stride *= 8; }
         }
@@ -888,7 +984,7 @@ __global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t
         while (__any(refine)) {
             if (refine) stride >>= 3;
             const uint64_t p = lo + (uint64_t)(l + 1) * stride;
-            const bool eq = refine && l < 7 && p < n_valid && elems[p].x == key;
+            const bool eq = refine && l < 7 && p < n_valid && keys[4 * p] == key;
             const unsigned k = __popc((unsigned)((__ballot(eq) >> gsh) & 0xFFull));
             if (refine) { lo += k * stride; if (stride == 1) refine = false; }
         }
@@ -911,57 +1007,97 @@ __device__ inline void sortkey32_origin(uint32_t sk, const SortKeyMap& km, doubl
     for (int j = 0; j < 3; ++j) org[j] = (double)c[j] * res;
 }
 
+// nine sums of one big segment per block (blocks stride over the list)
 __global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, const uint32_t* big_count, const uint4* elems, const uint32_t* seg_pos,
-                                                            const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, double* big_sums) {
+                                                            const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, double* sums) {
     __shared__ double sm[BIG_THREADS / 64][9];
     const uint32_t n_big = *big_count;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {       // (uniform over the block)
-    const uint32_t g = big_list[b];
-    const uint32_t s = seg_pos[g], e = seg_end[g];
-    int64_t key;
-    double o[3];
-    sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, o);
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * BIG_THREADS) {       // four elements in flight per lane, added in index order
-        uint4 v[4];
+        const uint32_t g = big_list[b];
+        const uint32_t s = seg_pos[g], e = seg_end[g];
+        int64_t key;
+        double o[3];
+        sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, o);
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i0 = s + threadIdx.x; i0 < e; i0 += 4 * BIG_THREADS) {       // four elements in flight per lane, added in index order
+            uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + u * BIG_THREADS;
-            v[u] = i < e ? elems[i] : make_uint4(0, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * BIG_THREADS;
+                v[u] = i < e ? elems[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * BIG_THREADS >= e) break;
+                const double d0 = (double)__uint_as_float(v[u].y) - o[0], d1 = (double)__uint_as_float(v[u].z) - o[1], d2 = (double)__uint_as_float(v[u].w) - o[2];
+                a[0] += d0; a[1] += d1; a[2] += d2;
+                a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+                a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u * BIG_THREADS >= e) break;
-            const double d0 = (double)__uint_as_float(v[u].y) - o[0], d1 = (double)__uint_as_float(v[u].z) - o[1], d2 = (double)__uint_as_float(v[u].w) - o[2];
+        for (int o2 = 32; o2 >= 1; o2 >>= 1)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o2);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sm[threadIdx.x >> 6][j] = a[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            double r = sm[0][threadIdx.x];
+            for (int w = 1; w < BIG_THREADS / 64; ++w) r += sm[w][threadIdx.x];
+            sums[(size_t)g * 9 + threadIdx.x] = r;          // straight into the segment's row
+        }
+        __syncthreads();
+    }
+}
+
+// One group of L lanes (L = 8 or 64 by the batch's mean points per voxel) per segment, groups striding over the segments:
+// strided sums in voxel-local float64 coordinates over the segment's contiguous elements, xor tree over the group — the
+// same per-lane order and tree as the 64-bit-key kernel above, so both paths give the same bits.  Row g of `sums`.
+__global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos, const uint32_t* seg_end,
+                                                        const int32_t* plan, SortKeyMap km, MapBuildCfg cfg, const uint32_t* big_pos, double* sums) {
+    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
+    const int L = seg_wide(nseg, n_valid) ? 64 : 8;
+    const int lane = threadIdx.x & 63, l = lane & (L - 1), gpw = 64 / L;      // groups per wave
+    const uint32_t groups = gridDim.x * 4u * (uint32_t)gpw;
+    for (uint32_t g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
+        const uint32_t g = g0 + (uint32_t)(lane / L);
+        const bool act = g < nseg;
+        uint32_t s = 0, e = 0;
+        double org[3] = {0, 0, 0};
+        if (act) {
+            s = seg_pos[g];
+            e = big_pos[g] == SEG_NONE ? seg_end[g] : s;          // a big segment is summed by k_big_sums32
+            int64_t key;
+            sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, org);
+        }
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = s + l; i < e; i += L) {
+            const uint4 v = elems[i];
+            const double d0 = (double)__uint_as_float(v.y) - org[0], d1 = (double)__uint_as_float(v.z) - org[1], d2 = (double)__uint_as_float(v.w) - org[2];
             a[0] += d0; a[1] += d1; a[2] += d2;
             a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
             a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
         }
-    }
+        for (int o = L >> 1; o >= 1; o >>= 1)
 #pragma unroll
-    for (int o2 = 32; o2 >= 1; o2 >>= 1)
+            for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
+        if (act && l == 0 && e != s) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o2);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) sm[threadIdx.x >> 6][j] = a[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) {
-        double r = sm[0][threadIdx.x];
-        for (int w = 1; w < BIG_THREADS / 64; ++w) r += sm[w][threadIdx.x];
-        big_sums[(size_t)b * 9 + threadIdx.x] = r;
-    }
-    __syncthreads();
+            for (int j = 0; j < 9; ++j) sums[(size_t)g * 9 + j] = a[j];
+        }
     }
 }
 
-// lane 0 of a group: ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the
-// table, UpdateMeanAndCov with what the voxel held.  Returns the slot; *fresh_entry / *fresh_voxel tell what was new.
+// ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the table,
+// UpdateMeanAndCov with what the voxel held.  Returns the slot; *fresh_entry / *fresh_voxel tell what was new.
 __device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, int64_t key, int64_t* keys, int32_t* counts, double* mean, double* cov,
-                                                uint64_t mask, bool* fresh_entry, bool* fresh_voxel) {
-    double mu[3] = {a[0] / nb, a[1] / nb, a[2] / nb};
-    double cv[6] = {0, 0, 0, 0, 0, 0};
+                                                uint64_t mask, bool* fresh_entry, bool* fresh_voxel, double mu[3], double cv[6], int32_t* n_total) {
+    mu[0] = a[0] / nb; mu[1] = a[1] / nb; mu[2] = a[2] / nb;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cv[j] = 0.0;
     if (nb > 1) {   // ComputeMeanAndCov (math_utils.h:55-72): sample covariance over (n-1)
         const double dn = (double)(nb - 1);
         cv[0] = (a[3] - a[0] * mu[0]) / dn; cv[1] = (a[4] - a[0] * mu[1]) / dn; cv[2] = (a[5] - a[0] * mu[2]) / dn;
@@ -1005,121 +1141,99 @@ __device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, i
 #pragma unroll
     for (int j = 0; j < 6; ++j) cp[j] = cv[j];
     counts[slot] = ntot;
+    *n_total = ntot;
     return (uint32_t)slot;
 }
 
-// One group of L lanes (L = 8 or 64, chosen on the device by k_seg_plan) per segment, groups striding over the segments:
-// strided sums in voxel-local float64 coordinates over the segment's contiguous elements, xor tree over the group — the
-// same per-lane order and tree as the 64-bit-key kernel below, so both paths give the same bits — then lane 0 merges.
-__global__ __launch_bounds__(256) void k_segment_merge32(const uint4* __restrict__ elems, const uint32_t* seg_pos, const uint32_t* seg_end, int32_t* plan,
-                                                         SortKeyMap km, MapBuildCfg cfg, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask,
-                                                         uint32_t* seg_slot, const uint32_t* big_pos, const double* big_sums) {
-    if (plan[PL_ABORT1]) return;
+// One voxel of the batch per thread: merge its sums into the table, then the regularised inverse + float32 payload.
+// Voxels that got their first points go on the fresh list (the ghost stage works on those only).  Decides for the whole
+// batch whether the table has room (n_entries: the host's exact count) and leaves the verdict in plan[PL_ABORT1].
+__global__ __launch_bounds__(256) void k_merge_finalize32(const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end, int32_t* plan, SortKeyMap km,
+                                                          MapBuildCfg cfg, const double* sums, VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean,
+                                                          double* cov, uint64_t cap, uint64_t n_entries, uint32_t* fresh_list) {
     const uint32_t nseg = (uint32_t)plan[PL_NSEG];
-    const int L = plan[PL_LANES];
-    const int lane = threadIdx.x & 63, l = lane & (L - 1), gpw = 64 / L;      // groups per wave
-    const uint32_t groups = gridDim.x * 4u * (uint32_t)gpw;
-    uint32_t n_new_vox = 0, n_new_ent = 0;
-    for (uint32_t g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
-        const uint32_t g = g0 + (uint32_t)(lane / L);
-        const bool act = g < nseg;
-        uint32_t s = 0, e = 0, bp = SEG_NONE;
-        int64_t key = 0;
-        double org[3] = {0, 0, 0};
-        if (act) {
-            s = seg_pos[g]; e = seg_end[g]; bp = big_pos[g];
+    const bool abort1 = (n_entries + nseg) * 2 > cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan[PL_ABORT1] = abort1 ? 1 : 0;
+    if (abort1) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t n_new_ent = 0;
+    for (uint32_t g0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); g0 < nseg; g0 += gridDim.x * blockDim.x) {     // (uniform over the wave)
+        const uint32_t g = g0 + (uint32_t)lane;
+        bool fv = false;
+        if (g < nseg) {
+            const uint32_t s = seg_pos[g], e = seg_end[g];
+            int64_t key;
+            double org[3], a[9], mu[3], cv[6];
             sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, org);
-        }
-        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const uint32_t e_loop = bp == SEG_NONE ? e : s;          // a big segment was summed by k_big_sums32
-        for (uint32_t i = s + l; i < e_loop; i += L) {
-            const uint4 v = elems[i];
-            const double d0 = (double)__uint_as_float(v.y) - org[0], d1 = (double)__uint_as_float(v.z) - org[1], d2 = (double)__uint_as_float(v.w) - org[2];
-            a[0] += d0; a[1] += d1; a[2] += d2;
-            a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
-            a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
-        }
-        for (int o = L >> 1; o >= 1; o >>= 1)
 #pragma unroll
-            for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o);
-        if (act && l == 0) {
-            if (bp != SEG_NONE) {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) a[j] = big_sums[(size_t)bp * 9 + j];
-            }
-            bool fe, fv;
-            seg_slot[g] = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, mask, &fe, &fv);
+            for (int j = 0; j < 9; ++j) a[j] = sums[(size_t)g * 9 + j];
+            bool fe;
+            int32_t ntot;
+            const uint32_t slot = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, cap - 1, &fe, &fv, mu, cv, &ntot);
+            finalize_slot(&slots[slot], ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
             n_new_ent += fe ? 1u : 0u;
-            n_new_vox += fv ? 1u : 0u;
         }
+        const unsigned long long b = __ballot(fv);               // one returning atomic per wave
+        uint32_t base = 0;
+        if (lane == 0 && b) base = atomicAdd((uint32_t*)&plan[PL_NEW_VOX], (uint32_t)__popcll(b));
+        base = __shfl(base, 0);
+        if (fv) fresh_list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = g;
     }
-    block_count_add(n_new_vox, &plan[PL_NEW_VOX]);
     block_count_add(n_new_ent, &plan[PL_NEW_ENT]);
 }
 
-// one voxel of the batch per lane: regularised inverse + payload from the merged statistics
-__global__ __launch_bounds__(256) void k_finalize_segments32(const uint32_t* seg_slot, const int32_t* plan, MapBuildCfg cfg, VoxSlot* slots,
-                                                             const int32_t* counts, const double* mean, const double* cov) {
-    if (plan[PL_ABORT1]) return;
-    const uint32_t nseg = (uint32_t)plan[PL_NSEG];
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nseg; g += gridDim.x * blockDim.x) {
-        const size_t slot = seg_slot[g];
-        double mu[3], cv[6];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) mu[j] = mean[slot * 3 + j];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) cv[j] = cov[slot * 6 + j];
-        finalize_slot(&slots[slot], counts[slot], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
-    }
-}
-
 // ------------------------------------------------------------------ ghost cells and links of a batch (all paths)
-// where the keys of a batch's voxels come from
+// where the keys of a batch's voxels come from, and which of them got their first points in this batch (only those can
+// need new ghost cells or links: every voxel's six neighbours are in the table from the moment it gets its first points)
 struct SegKeys {
     const uint4* elems; const uint32_t* seg_pos;           // fast path: sorted 16-byte elements + segment positions
     const uint64_t* sk64; const uint32_t* seg_start;       // 64-bit-key path: sorted compact keys + segment starts
     const int64_t* plain;                                   // a plain list of packed keys (map_restore)
     SortKeyMap km;
+    const int32_t* d_count;                                 // device word: number of items
+    const uint32_t* list;                                   // item i is voxel list[i] of the batch (nullptr: voxel i)
+    const uint32_t* fresh_flag;                             // nullptr, or per voxel: 0 = skip (it had points before)
 };
-__device__ inline int64_t seg_key(const SegKeys& K, uint32_t g) {
-    if (K.plain) return K.plain[g];
-    if (K.elems) return sortkey_to_packed((uint64_t)K.elems[K.seg_pos[g]].x, K.km);
-    return sortkey_to_packed(K.sk64[K.seg_start[g]], K.km);
+__device__ inline bool seg_item(const SegKeys& K, uint32_t i, int64_t* key) {
+    const uint32_t g = K.list ? K.list[i] : i;
+    if (K.fresh_flag && !K.fresh_flag[g]) return false;
+    if (K.plain) *key = K.plain[g];
+    else if (K.elems) *key = sortkey_to_packed((uint64_t)K.elems[K.seg_pos[g]].x, K.km);
+    else *key = sortkey_to_packed(K.sk64[K.seg_start[g]], K.km);
+    return true;
 }
 
-// one thread per (voxel of the batch, face direction): neighbours that are not in the table yet
-__global__ __launch_bounds__(256) void k_ghost_count(SegKeys K, const int32_t* d_nseg, const int64_t* keys, uint64_t mask, int32_t* plan) {
+// one thread per (new voxel of the batch, face direction): neighbours that are not in the table yet
+__global__ __launch_bounds__(256) void k_ghost_count(SegKeys K, const int64_t* keys, uint64_t mask, int32_t* plan) {
     if (plan[PL_ABORT1]) return;
-    const uint32_t nseg = (uint32_t)*d_nseg;
+    const uint32_t n_items = (uint32_t)*K.d_count;
     uint32_t missing = 0;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)nseg * 8; t += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)n_items * 8; t += (uint64_t)gridDim.x * blockDim.x) {
         const int d = (int)(t & 7);
-        if (d >= 6) continue;
-        int64_t nk;
-        if (neighbour_key(seg_key(K, (uint32_t)(t >> 3)), d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++missing;
+        int64_t key, nk;
+        if (d >= 6 || !seg_item(K, (uint32_t)(t >> 3), &key)) continue;
+        if (neighbour_key(key, d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++missing;
     }
     block_count_add(missing, &plan[PL_MISSING]);
 }
-// one thread: the voxel stage's counts join the map's counters; do the ghost cells fit?
-__global__ void k_ghost_plan(int32_t* plan, int32_t* map_counts, const int32_t* new_vox, const int32_t* new_ent, uint64_t cap) {
-    map_counts[0] += *new_vox;
-    map_counts[1] += *new_ent;
-    plan[PL_ABORT2] = (!plan[PL_ABORT1] && ((uint64_t)map_counts[1] + (uint64_t)plan[PL_MISSING]) * 2 > cap) ? 1 : 0;
-}
-// one thread per (voxel of the batch, face direction): find-or-insert the neighbour cell and link the two entries both
-// ways.  Every voxel's six neighbours are in the table from the moment it gets its first points, so an entry that is
-// created here (a ghost) can only touch voxels of this batch, whose own threads link it: no table-wide pass is needed.
-// Links between two ghost cells are never read (a ghost contributes nothing to a residual) and stay unset.
-__global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_nseg, int64_t* keys, VoxSlot* slots, uint64_t mask, int32_t* plan) {
-    if (plan[PL_ABORT1] || plan[PL_ABORT2]) return;
-    const uint32_t nseg = (uint32_t)*d_nseg;
+// one thread per (new voxel of the batch, face direction): find-or-insert the neighbour cell and link the two entries
+// both ways.  An entry that is created here (a ghost) can only touch voxels that are new in this batch, whose own threads
+// link it: no table-wide pass.  Links between two ghost cells are never read (a ghost contributes nothing to a residual)
+// and stay unset.  Decides first whether the ghost cells are sure to fit (verdict in plan[PL_ABORT2]).
+__global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_new_ent, int64_t* keys, VoxSlot* slots, uint64_t cap, uint64_t n_entries,
+                                                    int force, int32_t* plan) {
+    if (plan[PL_ABORT1]) return;
+    const bool abort2 = !force && (n_entries + (uint64_t)*d_new_ent + (uint64_t)plan[PL_MISSING]) * 2 > cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan[PL_ABORT2] = abort2 ? 1 : 0;
+    if (abort2) return;
+    const uint64_t mask = cap - 1;
+    const uint32_t n_items = (uint32_t)*K.d_count;
     uint32_t inserted = 0;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)nseg * 8; t += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)n_items * 8; t += (uint64_t)gridDim.x * blockDim.x) {
         const int d = (int)(t & 7);
-        if (d >= 6) continue;
-        const int64_t key = seg_key(K, (uint32_t)(t >> 3));
+        int64_t key, nk;
+        if (d >= 6 || !seg_item(K, (uint32_t)(t >> 3), &key)) continue;
         const uint32_t own = table_find(keys, mask, key);
-        int64_t nk;
         if (own == NDT_LINK_NONE || !neighbour_key(key, d, &nk)) continue;
         uint64_t slot = ndt_hash_key(nk) & mask;
         for (;;) {
@@ -1133,52 +1247,48 @@ __global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_
     }
     block_count_add(inserted, &plan[PL_NEW_GHOST]);
 }
-__global__ void k_ghost_done(int32_t* plan, int32_t* map_counts) { map_counts[1] += plan[PL_NEW_GHOST]; }
 __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 
-#define STAGE_BLOCKS 1024      // grid of the segment-striding kernels
+#define STAGE_BLOCKS 2048      // grid of the segment-striding kernels
 
-struct PlanWords { int32_t nseg, lanes, big, abort1, abort2, missing, new_vox, new_ent, new_ghost, n_vox, n_entries; };
-static int read_plan(const VoxelMap& m, const MapWork& w, PlanWords* p, hipStream_t s, std::string& err) {
-    int32_t a[8], c[2], ns;
-    HIP_TRY(hipMemcpyAsync(a, w.misc.as<int32_t>() + PL_LANES, sizeof a, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&ns, w.misc.as<int32_t>() + PL_NSEG, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c, m.d_n_vox, sizeof c, hipMemcpyDeviceToHost, s));
+struct PlanWords { int32_t nseg, sort_err, abort1, abort2, missing, new_vox, new_ent, new_ghost; };
+static int read_plan(const MapWork& w, const int32_t* d_new_vox, const int32_t* d_new_ent, PlanWords* p, hipStream_t s, std::string& err) {
+    int32_t a[6], lo[7], nv = 0, ne = 0;
+    HIP_TRY(hipMemcpyAsync(a, w.misc.as<int32_t>() + PL_ABORT1, sizeof a, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(lo, w.misc.as<int32_t>() + PL_NSEG, sizeof lo, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&nv, d_new_vox, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&ne, d_new_ent, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *p = PlanWords{ns, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], c[0], c[1]};
+    *p = PlanWords{lo[0], lo[PL_SORT_ERR - PL_NSEG], a[0], a[1], a[2], nv, ne, a[5]};
     return NDT_OK;
 }
 
-// Ghost cells + links for the batch whose voxels are already merged (their counts in *new_vox / *new_ent, device words), then
-// the one read-back of the call.  Grows the table and re-runs when the device found that the ghost cells might not fit.
-static int ghost_stage(VoxelMap& m, MapWork& w, SegKeys K, const int32_t* d_nseg, uint32_t nseg_ub, const int32_t* d_new_vox, const int32_t* d_new_ent,
-                       PlanWords* pw, hipStream_t s, std::string& err) {
+// Ghost cells + links for the batch whose voxels are already merged (their counts in *d_new_vox / *d_new_ent, device words),
+// then the one read-back of the call and the host's counters.  Grows the table and re-runs when the device found that the
+// ghost cells might not fit.
+static int ghost_stage(VoxelMap& m, MapWork& w, const SegKeys& K, uint32_t items_ub, const int32_t* d_new_vox, const int32_t* d_new_ent, PlanWords* pw,
+                       hipStream_t s, std::string& err) {
     int32_t* plan = w.misc.as<int32_t>();
-    const unsigned nb = (unsigned)std::min<uint64_t>(STAGE_BLOCKS, ((uint64_t)nseg_ub * 8 + 255) / 256);
-    k_ghost_count<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, (uint64_t)(m.cap - 1), plan);
-    k_ghost_plan<<<1, 1, 0, s>>>(plan, m.d_n_vox, d_new_vox, d_new_ent, (uint64_t)m.cap);
-    k_ghost_link<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, m.slots, (uint64_t)(m.cap - 1), plan);
-    k_ghost_done<<<1, 1, 0, s>>>(plan, m.d_n_vox);
+    const unsigned nb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(STAGE_BLOCKS, ((uint64_t)items_ub * 8 + 255) / 256));
+    k_ghost_count<<<nb, 256, 0, s>>>(K, m.keys, (uint64_t)(m.cap - 1), plan);
+    k_ghost_link<<<nb, 256, 0, s>>>(K, d_new_ent, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)m.n_entries, 0, plan);
     HIP_TRY(hipGetLastError());
-    int rc = read_plan(m, w, pw, s, err);
-    if (rc != NDT_OK) return rc;
-    if (!pw->abort1 && pw->abort2) {      // the voxels are in, their ghosts were not attempted: make room (links are rebuilt), then link
-        m.n_vox = pw->n_vox; m.n_entries = pw->n_entries;
-        rc = map_reserve(m, (size_t)pw->n_entries + (size_t)pw->missing, s, err);
+    int rc = read_plan(w, d_new_vox, d_new_ent, pw, s, err);
+    if (rc != NDT_OK || pw->abort1) return rc;
+    m.n_vox += pw->new_vox;
+    m.n_entries += pw->new_ent;
+    if (pw->abort2) {      // the voxels are in, their ghosts were not attempted: make room (all links are rebuilt), then link
+        rc = map_reserve(m, (size_t)m.n_entries + (size_t)pw->missing, s, err);
         if (rc != NDT_OK) return rc;
-        HIP_TRY(hipMemsetAsync(plan + PL_ABORT2, 0, 4, s));
-        k_ghost_link<<<nb, 256, 0, s>>>(K, d_nseg, m.keys, m.slots, (uint64_t)(m.cap - 1), plan);
-        k_ghost_done<<<1, 1, 0, s>>>(plan, m.d_n_vox);
+        k_ghost_link<<<nb, 256, 0, s>>>(K, d_new_ent, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)m.n_entries, 1, plan);
         HIP_TRY(hipGetLastError());
-        rc = read_plan(m, w, pw, s, err);
+        rc = read_plan(w, d_new_vox, d_new_ent, pw, s, err);
         if (rc != NDT_OK) return rc;
     }
-    if (!pw->abort1) { m.n_vox = pw->n_vox; m.n_entries = pw->n_entries; }
+    m.n_entries += pw->new_ghost;
     return NDT_OK;
 }
 
-// Stage 1 of every cloud ingest: staging (host records are copied; device records and SoA arrays are read in place),
-// bounding box of the cells, sort-key layout.  The one read-back every ingest needs: the radix pass count depends on it.
 struct IngestBox { const unsigned char* d_in; double* dRt; size_t n_valid; int32_t misc[8]; SortKeyMap km; int total_bits; uint64_t bbox_cells; };
 static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride, const double* R,
                        const double* t, bool zyx_order, bool write_keys, hipStream_t s, IngestBox* out, std::string& err) {
@@ -1198,7 +1308,7 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
         }
     }
     HIP_TRY(w.misc.ensure(256));
-    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_LANES, 0, 32, s));       // the plan words of this call start at zero
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 160, 0, 32, s));       // the plan words of this call (40..47) start at zero
     double* dRt = (double*)((char*)w.misc.p + 64);
     if (R) {
         double Rt[12];
@@ -1356,11 +1466,12 @@ static int map_merge_wide(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const
     k_scan_spine<<<1, SCAN_THREADS, 0, s>>>(w.scan_tmp.as<uint32_t>(), nbf, (uint32_t*)(plan + 9));
     HIP_TRY(hipGetLastError());
     SegKeys K{};
-    K.sk64 = sc.sorted_keys; K.seg_start = segs; K.km = sc.km;
+    K.sk64 = sc.sorted_keys; K.seg_start = segs; K.km = sc.km; K.d_count = plan + PL_NSEG; K.fresh_flag = w.flags.as<uint32_t>();
     PlanWords pw;
-    return ghost_stage(m, w, K, plan + PL_NSEG, nseg, plan + 8, plan + 9, &pw, s, err);
+    return ghost_stage(m, w, K, nseg, plan + 8, plan + 9, &pw, s, err);      // the table was reserved for the voxels above: abort1 stays 0
 }
 
+// Map build / keyframe merge.  One read-back for the bounding box, one at the end for everything the device decided.
 // Map build / keyframe merge.  One read-back for the bounding box, one at the end for everything the device decided.
 int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
                      size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
@@ -1374,61 +1485,89 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     const bool has_invalid = box.n_valid < n;
     if (box.total_bits + (has_invalid ? 1 : 0) > 32) return map_merge_wide(m, w, cfg, pts, soa_y, soa_z, n, stride, R, t, box, s, passes, err);
 
-    // ---- 16-byte elements {compact key, x, y, z} + the first digit's histograms
+    // ---- 16-byte elements {compact key, x, y, z} + the digit totals of every pass, then one kernel per radix pass
     const size_t n_valid = box.n_valid;
-    const int P = std::max(1, (box.total_bits + (has_invalid ? 1 : 0) + 7) / 8);
+    const int P = std::max(1, (box.total_bits + (has_invalid ? 1 : 0) + 7) / 8);      // <= 4
     if (passes) *passes = P;
-    // tiles: 4096 elements for big clouds; for a LiDAR scan 4096 too, so that its 256 x blocks histogram fits the one-block scan
-    const size_t rs_tile = (size_t)RS_THREADS * RS_ITEMS_BIG;
-    const unsigned nblk = (unsigned)((n + rs_tile - 1) / rs_tile);
-    const size_t nh = (size_t)256 * nblk;
+    const unsigned ntiles = (unsigned)((n + OS_TILE - 1) / OS_TILE);
+    const size_t status_words = (size_t)ntiles * 256;
     HIP_TRY(w.keys_a.ensure(n * 16)); HIP_TRY(w.keys_b.ensure(n * 16));
-    HIP_TRY(w.hist.ensure(nh * 4));
-    HIP_TRY(w.scan_tmp.ensure(((nh + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
+    // hist: [P][256] digit totals, [P] tickets (padded to 256 words); vals_a: the tiles' status words of every pass
+    HIP_TRY(w.hist.ensure((size_t)(OS_MAX_PASSES + 1) * 256 * 4));
+    HIP_TRY(w.vals_a.ensure((size_t)P * status_words * 8));
+    HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)(OS_MAX_PASSES + 1) * 256 * 4, s));
+    HIP_TRY(hipMemsetAsync(w.vals_a.p, 0, (size_t)P * status_words * 8, s));
     uint4* ea = w.keys_a.as<uint4>(); uint4* eb = w.keys_b.as<uint4>();
+    uint32_t* ghist = w.hist.as<uint32_t>();
+    uint32_t* tickets = ghist + OS_MAX_PASSES * 256;
+    int32_t* plan = w.misc.as<int32_t>();
     const uint32_t invalid_sk = has_invalid ? (uint32_t)(1ull << box.total_bits) : 0xFFFFFFFFu;
-    k_make_elems32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, cfg.kp, box.km, invalid_sk, ea,
-                                                             w.hist.as<uint32_t>(), nblk);
-    for (int p = 0; p < P; ++p) {
-        if (p) k_radix_hist32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ea, n, 8 * p, w.hist.as<uint32_t>(), nblk);
-        exclusive_scan_u32(w.hist.as<uint32_t>(), w.hist.as<uint32_t>(), nh, w.scan_tmp.as<uint32_t>(), nullptr, s);
-        k_radix_scatter32<RS_ITEMS_BIG><<<nblk, RS_THREADS, 0, s>>>(ea, n, 8 * p, w.hist.as<uint32_t>(), nblk, eb);
-        std::swap(ea, eb);
+    const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS - 1) / RS_THREADS);
+    k_make_elems32<<<nb_me, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, cfg.kp, box.km, invalid_sk, P, ea, ghist);
+    static const bool three_kernel_passes = getenv("NDT_NO_ONESWEEP") != nullptr;        // A/B switch
+    auto sort_three_kernels = [&](uint4*& a, uint4*& b) -> int {
+        const unsigned nblk = ntiles;
+        const size_t nh = (size_t)256 * nblk;
+        HIP_TRY(w.vals_b.ensure(nh * 4));
+        HIP_TRY(w.scan_tmp.ensure(((nh + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
+        for (int p = 0; p < P; ++p) {
+            k_radix_hist32<OS_ITEMS><<<nblk, RS_THREADS, 0, s>>>(a, n, 8 * p, w.vals_b.as<uint32_t>(), nblk);
+            exclusive_scan_u32(w.vals_b.as<uint32_t>(), w.vals_b.as<uint32_t>(), nh, w.scan_tmp.as<uint32_t>(), nullptr, s);
+            k_radix_scatter32<OS_ITEMS><<<nblk, RS_THREADS, 0, s>>>(a, n, 8 * p, w.vals_b.as<uint32_t>(), nblk, b);
+            std::swap(a, b);
+        }
+        HIP_TRY(hipGetLastError());
+        return NDT_OK;
+    };
+    if (three_kernel_passes) {
+        if ((rc = sort_three_kernels(ea, eb)) != NDT_OK) return rc;
+    } else {
+        for (int p = 0; p < P; ++p) {
+            k_onesweep32<<<ntiles, RS_THREADS, 0, s>>>(ea, eb, (uint32_t)n, 8 * p, ghist + p * 256, w.vals_a.as<unsigned long long>() + (size_t)p * status_words,
+                                                       tickets + p, plan + PL_SORT_ERR);
+            std::swap(ea, eb);
+        }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
 
-    // ---- segments (unordered), plan, ends, sums, merge, payloads
+    // ---- segments (unordered), ends, sums, merge + payloads, ghost cells of the new voxels
     const size_t nseg_ub = (size_t)std::min<uint64_t>(n_valid, box.bbox_cells);
     HIP_TRY(w.seg_start.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.flags.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.segid.ensure(nseg_ub * 4 + 16));
-    HIP_TRY(w.big_pos.ensure(nseg_ub * 4 + 16));
+    HIP_TRY(w.big_pos.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.big_sums.ensure(nseg_ub * 9 * 8 + 16));
     const size_t big_ub = n_valid / 512 + 1;                    // no more segments than this can be longer than the smaller threshold
-    HIP_TRY(w.big_list.ensure(big_ub * 4 + 16)); HIP_TRY(w.big_sums.ensure(big_ub * 9 * 8 + 16));
-    uint32_t* seg_pos = w.seg_start.as<uint32_t>(); uint32_t* seg_end = w.flags.as<uint32_t>(); uint32_t* seg_slot = w.segid.as<uint32_t>();
-    int32_t* plan = w.misc.as<int32_t>();
+    HIP_TRY(w.big_list.ensure(big_ub * 4 + 16));
+    uint32_t* seg_pos = w.seg_start.as<uint32_t>(); uint32_t* seg_end = w.flags.as<uint32_t>(); uint32_t* fresh_list = w.segid.as<uint32_t>();
+    double* sums = w.big_sums.as<double>();
     uint32_t* big_count = (uint32_t*)(plan + PL_BIGCOUNT);
     if (!m.cap) { rc = map_reserve(m, 1, s, err); if (rc != NDT_OK) return rc; }
-    const unsigned nbv = (unsigned)((n_valid + 255) / 256);
-    const unsigned nb_seg = (unsigned)std::min<uint64_t>(STAGE_BLOCKS, (nseg_ub * 8 + 255) / 256);
-    SegKeys K{};
-    K.elems = ea; K.seg_pos = seg_pos; K.km = box.km;
-    k_seg_heads32<<<nbv, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] was zeroed by k_bbox_reduce
-    k_seg_plan<<<1, 1, 0, s>>>(plan, m.d_n_vox, (uint32_t)n_valid, (uint64_t)m.cap);
-    k_seg_ends32<<<nb_seg, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
-    k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, ea, seg_pos, seg_end, box.km, cfg,
-                                                                                 w.big_sums.as<double>());
-    HIP_TRY(hipGetLastError());
+    const unsigned nb_heads = (unsigned)((n_valid + SH_THREADS * SH_ITEMS - 1) / (SH_THREADS * SH_ITEMS));
+    const unsigned nb_seg8 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(STAGE_BLOCKS, (nseg_ub * 8 + 255) / 256));
+    const unsigned nb_seg1 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(STAGE_BLOCKS, (nseg_ub + 255) / 256));
     PlanWords pw;
     for (int attempt = 0;; ++attempt) {
-        k_segment_merge32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, m.keys, m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), seg_slot,
-                                                       w.big_pos.as<uint32_t>(), w.big_sums.as<double>());
-        k_finalize_segments32<<<nb_seg, 256, 0, s>>>(seg_slot, plan, cfg, m.slots, m.counts, m.mean, m.cov);
+        if (attempt == 0 || pw.sort_err) {
+            k_seg_heads32<<<nb_heads, SH_THREADS, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] starts at zero
+            k_seg_ends32<<<nb_seg8, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
+            k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, ea, seg_pos, seg_end, box.km, cfg, sums);
+            k_segment_sums32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, seg_end, plan, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
+        }
+        k_merge_finalize32<<<nb_seg1, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, sums, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)m.cap,
+                                                   (uint64_t)m.n_entries, fresh_list);
         HIP_TRY(hipGetLastError());
-        rc = ghost_stage(m, w, K, plan + PL_NSEG, (uint32_t)nseg_ub, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
+        SegKeys K{};
+        K.elems = ea; K.seg_pos = seg_pos; K.km = box.km; K.d_count = plan + PL_NEW_VOX; K.list = fresh_list;
+        rc = ghost_stage(m, w, K, (uint32_t)nseg_ub, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
         if (rc != NDT_OK) return rc;
+        if (pw.sort_err) {
+            // a one-sweep pass gave up waiting (never seen): whatever was merged came from unsorted data, so this batch cannot be
+            // trusted; report it rather than continue
+            err = "radix sort: a tile waited too long for its predecessor";
+            return NDT_ERR_HIP;
+        }
         if (!pw.abort1) break;
         if (attempt >= 2) { err = "voxel table could not be sized for the batch"; return NDT_ERR_HIP; }
         // the device found that the batch's voxels might not fit (nothing was inserted): room for them and, at the usual
-        // ratio, their ghost cells; then the insert stages run again on the sorted data that is still in place
+        // ratio, their ghost cells; then the insert stages run again on the sorted data and sums that are still in place
         rc = map_reserve(m, (size_t)m.n_entries + (size_t)pw.nseg + (size_t)pw.nseg * 3 / 2, s, err);
         if (rc != NDT_OK) return rc;
         HIP_TRY(hipMemsetAsync(plan + PL_ABORT1, 0, 24, s));               // abort flags, missing, new_vox, new_ent, new_ghost
@@ -1609,13 +1748,14 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
     HIP_TRY(hipGetLastError());
     // every key is new (the blob was validated: distinct keys into a cleared map): n voxels, n table entries
     int32_t* plan = w.misc.as<int32_t>();
-    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_LANES, 0, 32, s));
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 160, 0, 32, s));
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_NSEG, 0, 28, s));       // nseg .. sort error
     k_set_word<<<1, 1, 0, s>>>(plan + PL_NSEG, (int32_t)n);
     k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_VOX, (int32_t)n);
     k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_ENT, (int32_t)n);
     HIP_TRY(hipGetLastError());
     SegKeys K{};
-    K.plain = w.keys_a.as<int64_t>();
+    K.plain = w.keys_a.as<int64_t>(); K.d_count = plan + PL_NSEG;
     PlanWords pw;
-    return ghost_stage(m, w, K, plan + PL_NSEG, (uint32_t)n, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
+    return ghost_stage(m, w, K, (uint32_t)n, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
 }
