@@ -65,7 +65,9 @@ void map_free(VoxelMap& m);
 hipError_t map_clear(VoxelMap& m, hipStream_t s);
 struct MapWork {
     DevBuf raw, tx, ty, tz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc, big_pos, big_list, big_sums;
+    int32_t* h_plan = nullptr;       // pinned: the 256-byte plan block (misc) as last read back
     void release() {
+        if (h_plan) { (void)hipHostFree(h_plan); h_plan = nullptr; }
         DevBuf* all[] = {&raw, &tx, &ty, &tz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums};
         for (DevBuf* b : all) b->release();
     }

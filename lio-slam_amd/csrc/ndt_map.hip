@@ -10,6 +10,8 @@
 // hash-slot claim.  All kernels are HBM-bound integer/byte work: coalesced 4/8-byte lanes, no MFMA.
 #include "ndt_internal.h"
 
+#include <string.h>
+
 #include <algorithm>
 #include <numeric>
 
@@ -721,7 +723,6 @@ static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; 
 #define PL_SORT_ERR 13   // a one-sweep pass gave up waiting for a predecessor tile (never seen; the host then sorts with the three-kernel passes)
 #define PL_ABORT1 42     // the batch's voxels may not fit the table: the insert stages did nothing, the host grows the table and re-runs them
 #define PL_ABORT2 43     // the ghost cells may not fit: the ghost stage did nothing, the host grows the table and re-runs it
-#define PL_MISSING 44    // neighbours of the batch's new voxels that are not in the table (upper bound of the ghosts to add)
 #define PL_NEW_VOX 45    // voxels that got their first points (= length of the fresh list)
 #define PL_NEW_ENT 46    // table entries created for voxels
 #define PL_NEW_GHOST 47  // table entries created for ghost cells
@@ -757,15 +758,22 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(unsigned d, bool 
 // LDS histogram add with same-digit lanes of a wave combined first (a LiDAR ring's consecutive points share their digit:
 // plain LDS atomics would serialise 64 ways)
 __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act) {
-    const unsigned long long m = same_digit_lanes(d, act);
+    const unsigned long long am = __ballot(act);
+    if (!am) return;
     const int lane = threadIdx.x & 63;
+    const unsigned d0 = (unsigned)__shfl((int)d, __ffsll((long long)am) - 1);
+    if (!__any(act && d != d0)) {          // all active lanes share one digit (the usual case for the higher digits): one add
+        if (lane == __ffsll((long long)am) - 1) atomicAdd(&h[d0], (uint32_t)__popcll(am));
+        return;
+    }
+    const unsigned long long m = same_digit_lanes(d, act);
     if (act && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(m));
 }
 
 #define OS_ITEMS 16
 #define OS_TILE (RS_THREADS * OS_ITEMS)        // 4096 elements per tile
 #define OS_MAX_PASSES 4
-#define ME_MAX_BLOCKS 512                       // blocks of k_make_elems32: bounds the same-address adds into the digit totals
+#define ME_MAX_BLOCKS 1024                      // blocks of k_make_elems32: bounds the same-address adds into the digit totals
 
 // elements + digit totals of every pass (ghist[p][256]); blocks stride over the tiles
 __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T,
@@ -775,19 +783,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char
 #pragma unroll
     for (int p = 0; p < OS_MAX_PASSES; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
-    for (size_t base = (size_t)blockIdx.x * RS_THREADS; base < n; base += (size_t)gridDim.x * RS_THREADS) {      // (uniform over the block)
-        const size_t i = base + threadIdx.x;
-        const bool act = i < n;
-        uint32_t sk = invalid_sk;
-        if (act) {
-            float x, y, z;
-            int32_t c[3];
-            if (load_target_point(raw, soa_y, soa_z, i, stride, has_T, Rt, kp, x, y, z, c))
-                sk = ((uint32_t)(c[km.axis[0]] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint32_t)(c[km.axis[1]] - km.mn[1]) << km.bits[2]) |
-                     (uint32_t)(c[km.axis[2]] - km.mn[2]);
-            elems[i] = make_uint4(sk, __float_as_uint(x), __float_as_uint(y), __float_as_uint(z));
+    // four points per thread in flight; blocks stride over the input
+    for (size_t base = (size_t)blockIdx.x * (RS_THREADS * 4); base < n; base += (size_t)gridDim.x * (RS_THREADS * 4)) {      // (uniform over the block)
+        float x[4], y[4], z[4];
+        int32_t c[4][3];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base + (size_t)u * RS_THREADS + threadIdx.x;
+            ok[u] = i < n && load_target_point(raw, soa_y, soa_z, i, stride, has_T, Rt, kp, x[u], y[u], z[u], c[u]);
         }
-        for (int p = 0; p < passes; ++p) wave_hist_add(h[p], (sk >> (8 * p)) & 255u, act);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = base + (size_t)u * RS_THREADS + threadIdx.x;
+            const bool act = i < n;
+            uint32_t sk = invalid_sk;
+            if (ok[u])
+                sk = ((uint32_t)(c[u][km.axis[0]] - km.mn[0]) << (km.bits[1] + km.bits[2])) | ((uint32_t)(c[u][km.axis[1]] - km.mn[1]) << km.bits[2]) |
+                     (uint32_t)(c[u][km.axis[2]] - km.mn[2]);
+            if (act) elems[i] = make_uint4(sk, __float_as_uint(x[u]), __float_as_uint(y[u]), __float_as_uint(z[u]));
+            for (int p = 0; p < passes; ++p) wave_hist_add(h[p], (sk >> (8 * p)) & 255u, act);
+        }
     }
     __syncthreads();
     for (int p = 0; p < passes; ++p)
@@ -806,70 +822,86 @@ __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
                                                            const uint32_t* __restrict__ ghist, unsigned long long* status, uint32_t* ticket, int32_t* err) {
     __shared__ uint32_t s_tile;
-    __shared__ uint32_t h[256];
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t wcnt[4][256];      // per wave: running count of each digit, then the wave's first output position of it
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    h[threadIdx.x] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const size_t base = (size_t)tile * OS_TILE;
+    // element order inside a tile: (wave, round, lane) — every wave owns 1024 consecutive elements, so ranking needs no
+    // block barrier per round
+    const size_t base = (size_t)tile * OS_TILE + (size_t)w * (64 * OS_ITEMS) + lane;
     uint4 e[OS_ITEMS];
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; ++r) {
-        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        const size_t i = base + (size_t)r * 64;
         e[r] = i < n ? in[i] : make_uint4(0, 0, 0, 0);
     }
+    uint32_t rank[OS_ITEMS];               // rank of the element among the wave's elements of the same digit, in element order
+    volatile uint32_t* wc = wcnt[w];
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; ++r) {
-        const bool act = base + (size_t)r * RS_THREADS + threadIdx.x < n;
-        wave_hist_add(h, (e[r].x >> shift) & 255u, act);
+        const bool act = base + (size_t)r * 64 < n;
+        const unsigned d = (e[r].x >> shift) & 255u;
+        const unsigned long long am = __ballot(act);
+        const int first = am ? __ffsll((long long)am) - 1 : 0;
+        const unsigned d0 = (unsigned)__shfl((int)d, first);
+        unsigned long long m;
+        if (!__any(act && d != d0)) m = am;                       // one digit in the whole wave: the usual case for the higher digits
+        else m = same_digit_lanes(d, act);
+        const uint32_t before = act ? wc[d] : 0u;
+        rank[r] = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        __builtin_amdgcn_wave_barrier();
+        if (act && (m & ((1ull << lane) - 1ull)) == 0ull) wc[d] = before + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // this thread owns digit threadIdx.x: global base of the digit + what the earlier tiles hold of it
     const uint32_t excl = block_exclusive_scan_256(ghist[threadIdx.x], nullptr);
-    const unsigned long long cnt = h[threadIdx.x];
+    const uint32_t c0 = wcnt[0][threadIdx.x], c1 = wcnt[1][threadIdx.x], c2 = wcnt[2][threadIdx.x], c3 = wcnt[3][threadIdx.x];
+    const unsigned long long cnt = (unsigned long long)c0 + c1 + c2 + c3;
     unsigned long long* mine = status + (size_t)tile * 256 + threadIdx.x;
     unsigned long long before = 0;
     if (tile == 0) {
         __hip_atomic_store(mine, OS_PRE | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         __hip_atomic_store(mine, OS_AGG | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // look back eight tiles at a time (eight loads in flight: a walk of one dependent load per tile would cost the
+        // later tiles of a small launch a microsecond per predecessor)
         int spins = 0;
-        for (uint32_t t = tile; t-- > 0;) {
-            unsigned long long v;
-            for (;;) {
-                v = __hip_atomic_load(status + (size_t)t * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v >> 62) break;
-                if (++spins > OS_SPIN_LIMIT) { *err = 1; v = OS_PRE; break; }
-                __builtin_amdgcn_s_sleep(1);
+        bool done = false;
+        for (uint32_t t1 = tile; t1 > 0 && !done;) {
+            const uint32_t nb = t1 < 8u ? t1 : 8u;
+            unsigned long long v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j)
+                v[j] = j < nb ? __hip_atomic_load(status + (size_t)(t1 - 1 - j) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (j >= nb || done) break;
+                while (!(v[j] >> 62)) {               // not published yet: wait for this one (bounded)
+                    if (++spins > OS_SPIN_LIMIT) { *err = 1; v[j] = OS_PRE; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    v[j] = __hip_atomic_load(status + (size_t)(t1 - 1 - j) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                before += v[j] & OS_VAL;
+                if ((v[j] >> 62) == 2ull) done = true;
             }
-            before += v & OS_VAL;
-            if ((v >> 62) == 2ull) break;
+            t1 -= nb;
         }
         __hip_atomic_store(mine, OS_PRE | (before + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    running[threadIdx.x] = excl + (uint32_t)before;
+    __syncthreads();                       // (block_exclusive_scan_256's shared words and every wave's counts are read)
+    const uint32_t p0 = excl + (uint32_t)before;
+    wcnt[0][threadIdx.x] = p0; wcnt[1][threadIdx.x] = p0 + c0; wcnt[2][threadIdx.x] = p0 + c0 + c1; wcnt[3][threadIdx.x] = p0 + c0 + c1 + c2;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; ++r) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
-        __syncthreads();
-        const bool act = base + (size_t)r * RS_THREADS + threadIdx.x < n;
-        const unsigned d = (e[r].x >> shift) & 255u;
-        const unsigned long long m = same_digit_lanes(d, act);
-        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (act && rank == 0) wcnt[w][d] = __popcll(m);
-        __syncthreads();
-        if (act) {
-            uint32_t pos = running[d] + rank;
-            for (int j = 0; j < w; ++j) pos += wcnt[j][d];
+        if (base + (size_t)r * 64 < n) {
+            const uint32_t pos = wcnt[w][(e[r].x >> shift) & 255u] + rank[r];
             if (pos < n) out[pos] = e[r];        // (always, unless a wait ran out)
         }
-        __syncthreads();
-        running[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
     }
 }
 
@@ -957,7 +989,7 @@ __global__ __launch_bounds__(SH_THREADS) void k_seg_heads32(const uint4* elems, 
 
 // what the segment kernels derive from the segment count, each for itself (no planning kernel in between)
 __device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 24; }   // 64 lanes per segment, else 8
-__device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? 2048u : 512u; }   // <= 32 / 64 trips
+__device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? 2048u : 256u; }   // <= 32 trips of a group
 
 // end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
 #define SEG_NONE 0xFFFFFFFFu
@@ -1074,12 +1106,21 @@ __global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict_
             sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, org);
         }
         double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = s + l; i < e; i += L) {
-            const uint4 v = elems[i];
-            const double d0 = (double)__uint_as_float(v.y) - org[0], d1 = (double)__uint_as_float(v.z) - org[1], d2 = (double)__uint_as_float(v.w) - org[2];
-            a[0] += d0; a[1] += d1; a[2] += d2;
-            a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
-            a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+        for (uint32_t i0 = s + l; i0 < e; i0 += 4 * L) {          // four elements in flight per lane, added in index order
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * L;
+                v[u] = i < e ? elems[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * L >= e) break;
+                const double d0 = (double)__uint_as_float(v[u].y) - org[0], d1 = (double)__uint_as_float(v[u].z) - org[1], d2 = (double)__uint_as_float(v[u].w) - org[2];
+                a[0] += d0; a[1] += d1; a[2] += d2;
+                a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+                a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+            }
         }
         for (int o = L >> 1; o >= 1; o >>= 1)
 #pragma unroll
@@ -1203,27 +1244,16 @@ __device__ inline bool seg_item(const SegKeys& K, uint32_t i, int64_t* key) {
     return true;
 }
 
-// one thread per (new voxel of the batch, face direction): neighbours that are not in the table yet
-__global__ __launch_bounds__(256) void k_ghost_count(SegKeys K, const int64_t* keys, uint64_t mask, int32_t* plan) {
-    if (plan[PL_ABORT1]) return;
-    const uint32_t n_items = (uint32_t)*K.d_count;
-    uint32_t missing = 0;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)n_items * 8; t += (uint64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(t & 7);
-        int64_t key, nk;
-        if (d >= 6 || !seg_item(K, (uint32_t)(t >> 3), &key)) continue;
-        if (neighbour_key(key, d, &nk) && table_find(keys, mask, nk) == NDT_LINK_NONE) ++missing;
-    }
-    block_count_add(missing, &plan[PL_MISSING]);
-}
 // one thread per (new voxel of the batch, face direction): find-or-insert the neighbour cell and link the two entries
 // both ways.  An entry that is created here (a ghost) can only touch voxels that are new in this batch, whose own threads
 // link it: no table-wide pass.  Links between two ghost cells are never read (a ghost contributes nothing to a residual)
-// and stay unset.  Decides first whether the ghost cells are sure to fit (verdict in plan[PL_ABORT2]).
-__global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_new_ent, int64_t* keys, VoxSlot* slots, uint64_t cap, uint64_t n_entries,
-                                                    int force, int32_t* plan) {
+// and stay unset.  Goes ahead whenever the table cannot overflow even if every neighbour were new (at most six ghosts per
+// new voxel, kept under 7/8 of the capacity); the host brings the load factor back under 1/2 afterwards.  Verdict in
+// plan[PL_ABORT2].
+__global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_new_vox, const int32_t* d_new_ent, int64_t* keys, VoxSlot* slots, uint64_t cap,
+                                                    uint64_t n_entries, int32_t* plan) {
     if (plan[PL_ABORT1]) return;
-    const bool abort2 = !force && (n_entries + (uint64_t)*d_new_ent + (uint64_t)plan[PL_MISSING]) * 2 > cap;
+    const bool abort2 = (n_entries + (uint64_t)*d_new_ent + 6ull * (uint64_t)*d_new_vox) * 8 > cap * 7;
     if (blockIdx.x == 0 && threadIdx.x == 0) plan[PL_ABORT2] = abort2 ? 1 : 0;
     if (abort2) return;
     const uint64_t mask = cap - 1;
@@ -1251,44 +1281,45 @@ __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 
 #define STAGE_BLOCKS 2048      // grid of the segment-striding kernels
 
-struct PlanWords { int32_t nseg, sort_err, abort1, abort2, missing, new_vox, new_ent, new_ghost; };
-static int read_plan(const MapWork& w, const int32_t* d_new_vox, const int32_t* d_new_ent, PlanWords* p, hipStream_t s, std::string& err) {
-    int32_t a[6], lo[7], nv = 0, ne = 0;
-    HIP_TRY(hipMemcpyAsync(a, w.misc.as<int32_t>() + PL_ABORT1, sizeof a, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(lo, w.misc.as<int32_t>() + PL_NSEG, sizeof lo, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&nv, d_new_vox, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&ne, d_new_ent, 4, hipMemcpyDeviceToHost, s));
+struct PlanWords { int32_t nseg, sort_err, abort1, abort2, new_vox, new_ent, new_ghost; };
+// the one read-back of a call: the whole 256-byte plan block in one copy into pinned memory
+static int read_plan(MapWork& w, int new_vox_word, int new_ent_word, PlanWords* p, hipStream_t s, std::string& err) {
+    if (!w.h_plan) HIP_TRY(hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, 256, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *p = PlanWords{lo[0], lo[PL_SORT_ERR - PL_NSEG], a[0], a[1], a[2], nv, ne, a[5]};
+    const int32_t* a = w.h_plan;
+    *p = PlanWords{a[PL_NSEG], a[PL_SORT_ERR], a[PL_ABORT1], a[PL_ABORT2], a[new_vox_word], a[new_ent_word], a[PL_NEW_GHOST]};
     return NDT_OK;
 }
 
-// Ghost cells + links for the batch whose voxels are already merged (their counts in *d_new_vox / *d_new_ent, device words),
-// then the one read-back of the call and the host's counters.  Grows the table and re-runs when the device found that the
-// ghost cells might not fit.
-static int ghost_stage(VoxelMap& m, MapWork& w, const SegKeys& K, uint32_t items_ub, const int32_t* d_new_vox, const int32_t* d_new_ent, PlanWords* pw,
-                       hipStream_t s, std::string& err) {
+// Ghost cells + links for the batch whose voxels are already merged (their counts in plan words new_vox_word / new_ent_word),
+// then the one read-back of the call and the host's counters.  Grows the table first when the device found that the ghost
+// cells might overflow it, and afterwards when the load factor went over 1/2.
+static int ghost_stage(VoxelMap& m, MapWork& w, const SegKeys& K, uint32_t items_ub, int new_vox_word, int new_ent_word, PlanWords* pw, hipStream_t s,
+                       std::string& err) {
     int32_t* plan = w.misc.as<int32_t>();
     const unsigned nb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(STAGE_BLOCKS, ((uint64_t)items_ub * 8 + 255) / 256));
-    k_ghost_count<<<nb, 256, 0, s>>>(K, m.keys, (uint64_t)(m.cap - 1), plan);
-    k_ghost_link<<<nb, 256, 0, s>>>(K, d_new_ent, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)m.n_entries, 0, plan);
+    k_ghost_link<<<nb, 256, 0, s>>>(K, plan + new_vox_word, plan + new_ent_word, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)m.n_entries, plan);
     HIP_TRY(hipGetLastError());
-    int rc = read_plan(w, d_new_vox, d_new_ent, pw, s, err);
+    int rc = read_plan(w, new_vox_word, new_ent_word, pw, s, err);
     if (rc != NDT_OK || pw->abort1) return rc;
     m.n_vox += pw->new_vox;
     m.n_entries += pw->new_ent;
     if (pw->abort2) {      // the voxels are in, their ghosts were not attempted: make room (all links are rebuilt), then link
-        rc = map_reserve(m, (size_t)m.n_entries + (size_t)pw->missing, s, err);
+        rc = map_reserve(m, (size_t)m.n_entries + 6 * (size_t)pw->new_vox, s, err);
         if (rc != NDT_OK) return rc;
-        k_ghost_link<<<nb, 256, 0, s>>>(K, d_new_ent, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)m.n_entries, 1, plan);
+        k_ghost_link<<<nb, 256, 0, s>>>(K, plan + new_vox_word, plan + new_ent_word, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)(m.n_entries - pw->new_ent), plan);
         HIP_TRY(hipGetLastError());
-        rc = read_plan(w, d_new_vox, d_new_ent, pw, s, err);
+        rc = read_plan(w, new_vox_word, new_ent_word, pw, s, err);
         if (rc != NDT_OK) return rc;
+        if (pw->abort2) { err = "voxel table could not be sized for the batch's ghost cells"; return NDT_ERR_HIP; }
     }
     m.n_entries += pw->new_ghost;
-    return NDT_OK;
+    return map_reserve(m, (size_t)m.n_entries, s, err);          // load factor back under 1/2 if the ghosts pushed it over (rare)
 }
 
+// Stage 1 of every cloud ingest: staging (host records are copied; device records and SoA arrays are read in place),
+// bounding box of the cells, sort-key layout.  The one read-back every ingest needs: the radix pass count depends on it.
 struct IngestBox { const unsigned char* d_in; double* dRt; size_t n_valid; int32_t misc[8]; SortKeyMap km; int total_bits; uint64_t bbox_cells; };
 static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride, const double* R,
                        const double* t, bool zyx_order, bool write_keys, hipStream_t s, IngestBox* out, std::string& err) {
@@ -1330,8 +1361,17 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
     }
     k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out->misc, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
+    if (!w.h_plan) HIP_TRY(hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault));
+    if (!write_keys) {       // fast path ahead: its digit totals, tickets and tile status words are zeroed while the host waits
+        const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+        HIP_TRY(w.hist.ensure((size_t)(OS_MAX_PASSES + 1) * 256 * 4));
+        HIP_TRY(w.vals_a.ensure((size_t)OS_MAX_PASSES * ntiles * 256 * 8));
+        HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)(OS_MAX_PASSES + 1) * 256 * 4, s));
+        HIP_TRY(hipMemsetAsync(w.vals_a.p, 0, (size_t)OS_MAX_PASSES * ntiles * 256 * 8, s));
+    }
+    HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out->misc, w.h_plan, sizeof out->misc);
     out->d_in = d_in; out->dRt = dRt;
     out->n_valid = (size_t)out->misc[6];
     out->total_bits = 0; out->bbox_cells = 1;
@@ -1468,7 +1508,7 @@ static int map_merge_wide(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const
     SegKeys K{};
     K.sk64 = sc.sorted_keys; K.seg_start = segs; K.km = sc.km; K.d_count = plan + PL_NSEG; K.fresh_flag = w.flags.as<uint32_t>();
     PlanWords pw;
-    return ghost_stage(m, w, K, nseg, plan + 8, plan + 9, &pw, s, err);      // the table was reserved for the voxels above: abort1 stays 0
+    return ghost_stage(m, w, K, nseg, 8, 9, &pw, s, err);      // the table was reserved for the voxels above: abort1 stays 0
 }
 
 // Map build / keyframe merge.  One read-back for the bounding box, one at the end for everything the device decided.
@@ -1493,16 +1533,13 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     const size_t status_words = (size_t)ntiles * 256;
     HIP_TRY(w.keys_a.ensure(n * 16)); HIP_TRY(w.keys_b.ensure(n * 16));
     // hist: [P][256] digit totals, [P] tickets (padded to 256 words); vals_a: the tiles' status words of every pass
-    HIP_TRY(w.hist.ensure((size_t)(OS_MAX_PASSES + 1) * 256 * 4));
-    HIP_TRY(w.vals_a.ensure((size_t)P * status_words * 8));
-    HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)(OS_MAX_PASSES + 1) * 256 * 4, s));
-    HIP_TRY(hipMemsetAsync(w.vals_a.p, 0, (size_t)P * status_words * 8, s));
+    // (hist and vals_a were sized and zeroed in ingest_bbox, before the host waited for the bounding box)
     uint4* ea = w.keys_a.as<uint4>(); uint4* eb = w.keys_b.as<uint4>();
     uint32_t* ghist = w.hist.as<uint32_t>();
     uint32_t* tickets = ghist + OS_MAX_PASSES * 256;
     int32_t* plan = w.misc.as<int32_t>();
     const uint32_t invalid_sk = has_invalid ? (uint32_t)(1ull << box.total_bits) : 0xFFFFFFFFu;
-    const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS - 1) / RS_THREADS);
+    const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));       // >= 8 points per thread
     k_make_elems32<<<nb_me, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, cfg.kp, box.km, invalid_sk, P, ea, ghist);
     static const bool three_kernel_passes = getenv("NDT_NO_ONESWEEP") != nullptr;        // A/B switch
     auto sort_three_kernels = [&](uint4*& a, uint4*& b) -> int {
@@ -1534,7 +1571,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     const size_t nseg_ub = (size_t)std::min<uint64_t>(n_valid, box.bbox_cells);
     HIP_TRY(w.seg_start.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.flags.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.segid.ensure(nseg_ub * 4 + 16));
     HIP_TRY(w.big_pos.ensure(nseg_ub * 4 + 16)); HIP_TRY(w.big_sums.ensure(nseg_ub * 9 * 8 + 16));
-    const size_t big_ub = n_valid / 512 + 1;                    // no more segments than this can be longer than the smaller threshold
+    const size_t big_ub = n_valid / 256 + 1;                    // no more segments than this can be longer than the smaller threshold
     HIP_TRY(w.big_list.ensure(big_ub * 4 + 16));
     uint32_t* seg_pos = w.seg_start.as<uint32_t>(); uint32_t* seg_end = w.flags.as<uint32_t>(); uint32_t* fresh_list = w.segid.as<uint32_t>();
     double* sums = w.big_sums.as<double>();
@@ -1556,7 +1593,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         HIP_TRY(hipGetLastError());
         SegKeys K{};
         K.elems = ea; K.seg_pos = seg_pos; K.km = box.km; K.d_count = plan + PL_NEW_VOX; K.list = fresh_list;
-        rc = ghost_stage(m, w, K, (uint32_t)nseg_ub, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
+        rc = ghost_stage(m, w, K, (uint32_t)nseg_ub, PL_NEW_VOX, PL_NEW_ENT, &pw, s, err);
         if (rc != NDT_OK) return rc;
         if (pw.sort_err) {
             // a one-sweep pass gave up waiting (never seen): whatever was merged came from unsorted data, so this batch cannot be
@@ -1570,7 +1607,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         // ratio, their ghost cells; then the insert stages run again on the sorted data and sums that are still in place
         rc = map_reserve(m, (size_t)m.n_entries + (size_t)pw.nseg + (size_t)pw.nseg * 3 / 2, s, err);
         if (rc != NDT_OK) return rc;
-        HIP_TRY(hipMemsetAsync(plan + PL_ABORT1, 0, 24, s));               // abort flags, missing, new_vox, new_ent, new_ghost
+        HIP_TRY(hipMemsetAsync(plan + PL_ABORT1, 0, 24, s));               // abort flags, new_vox, new_ent, new_ghost
     }
     return NDT_OK;
 }
@@ -1757,5 +1794,5 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
     SegKeys K{};
     K.plain = w.keys_a.as<int64_t>(); K.d_count = plan + PL_NSEG;
     PlanWords pw;
-    return ghost_stage(m, w, K, (uint32_t)n, plan + PL_NEW_VOX, plan + PL_NEW_ENT, &pw, s, err);
+    return ghost_stage(m, w, K, (uint32_t)n, PL_NEW_VOX, PL_NEW_ENT, &pw, s, err);
 }
