@@ -534,7 +534,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
     unpack_acc(st->acc, out->H, out->b);
     out->chi2 = st->acc[ACC_CHI2];
     out->n_effective = (int64_t)st->acc[ACC_NEFF];
-    out->last_dx_norm = loop.dx_norm;
+    out->last_dx_norm = sqrt(loop.dx_norm2);
     out->iterations = loop.iter;
     out->converged = loop.converged;
     out->status = loop.status;
@@ -922,7 +922,7 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
         unpack_acc(fin->acc, out->H, out->b);
         out->chi2 = fin->acc[ACC_CHI2];
         out->n_effective = (int64_t)fin->acc[ACC_NEFF];
-        out->last_dx_norm = loop[p].dx_norm;
+        out->last_dx_norm = sqrt(loop[p].dx_norm2);
         out->iterations = loop[p].iter;
         out->converged = loop[p].converged;
         out->status = loop[p].status;

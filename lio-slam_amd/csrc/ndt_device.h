@@ -38,7 +38,7 @@ struct GnState {          // one per alignment problem, lives in HBM for the who
     double t[3];
     double dx[6];
     double acc[ACC_N];    // reduced accumulators of the last evaluation
-    double dx_norm;
+    double dx_norm2;      // |dx|^2 of the last step
     int32_t iter;         // Gauss-Newton steps taken
     int32_t done;         // 1: loop finished (converged, cap reached or failed) -> later launches are no-ops
     int32_t converged;

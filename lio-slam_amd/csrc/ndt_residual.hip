@@ -296,11 +296,20 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
 // between st_in and st_out; block 0 publishes st_out), then runs the residual pass at the new pose.  One launch per
 // iteration instead of two: the 4 us one-block kernel, its launch gap and its end-of-kernel write-back leave the
 // critical path; the price is ~60 KB of L2 reads and one serial solve per block.  n_prev = 0: no pending step.
-__device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp);
-__device__ __forceinline__ double hb_entry(const double* R, const double* raw, int e);
-__device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
+template <int RG> __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* st, const SolveParams& sp, bool do_solve);
+__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
 
 struct InitPose { double Rt[12]; int use; };
+
+// Diagnostic build only (-DNDT_STAMPS, tools/exp_stamps.py): s_memtime at the phase boundaries of the chained launch, from
+// thread 0 of two blocks, into a buffer no other code reads.  The product library is built without it.
+#ifdef NDT_STAMPS
+__device__ unsigned long long g_ndt_stamps[2][8];
+#define STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) g_ndt_stamps[blockIdx.x ? 1 : 0][k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ndt_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ndt_stamps), sizeof(g_ndt_stamps)); }
+#else
+#define STAMP(k) do { } while (0)
+#endif
 static_assert(offsetof(GnState, R) == 0 && offsetof(GnState, t) == 72, "InitPose fills the first twelve words of GnState");
 
 template <int K, bool LINKED>
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
     __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
     __shared__ GnState sst;
+    STAMP(0);
     int i = blockIdx.x * RES1_THREADS + threadIdx.x;
     float xf = 0.f, yf = 0.f, zf = 0.f;
     if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
@@ -320,19 +330,15 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     // which saves the host-to-device copy in front of the loop (R[9], t[3] are the first twelve words; the rest is zero)
     if (threadIdx.x < ST_WORDS)
         ((double*)&sst)[threadIdx.x] = init.use ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : ((const double*)st_in)[threadIdx.x];
-    if (n_prev > 0) reduce_rows32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
+    if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
     else __syncthreads();
-    if (n_prev > 0) {          // (uniform) world-frame sums -> H, b: one lane per entry; sst still holds the pose the rows were computed at
-        if (threadIdx.x < ACC_N && !sst.done) sm[1][threadIdx.x] = hb_entry(sst.R, sm[0], threadIdx.x);
-        __syncthreads();
-    }
-    if (n_prev > 0 && threadIdx.x == 0 && !sst.done) {
-        double acc0[ACC_N];
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) { acc0[j] = sm[1][j]; sst.acc[j] = acc0[j]; }
-        gn_step(&sst, acc0, sp);
-    }
+    STAMP(1);
+    // (uniform) the rest of the previous step runs in the block's first wave, with no block barrier until the pose is out:
+    // column tree, world-frame sums -> H, b (sst still holds the pose the rows were computed at), Gauss-Newton step
+    if (n_prev > 0 && threadIdx.x < 64 && !sst.done) wave0_finish<16>(sm, &sst, sp, true);
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     if (blockIdx.x == 0 && threadIdx.x < ST_WORDS) ((double*)st_out)[threadIdx.x] = ((const double*)&sst)[threadIdx.x];
     if (sst.done) return;
     Pose P;
@@ -352,7 +358,9 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
         i += gridDim.x * RES1_THREADS;
         if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
     }
+    STAMP(4);
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
+    STAMP(5);
 }
 
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
@@ -454,14 +462,50 @@ void launch_residual_chain(const float* x, const float* y, const float* z, int n
 
 // ------------------------------------------------------------------ fixed-order final sum + Gauss-Newton step
 
-// 6x6 SPD solve, LDL^T with reciprocal pivots (6 divisions, no square roots); false if a pivot is not positive
+// 1 / x for a finite positive x: hardware estimate + two Newton steps (full double precision to an ulp or two; the IEEE
+// division expands to five times as many instructions, and the Gauss-Newton step sits on every iteration's critical
+// path: one lane, one dependent chain).  The step is compared with the oracle at 1e-4 m / 1e-5 rad, not bit for bit.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// sin and cos of a rotation step: Taylor series to x^19 / x^18 up to 0.8 rad (truncation < 1e-20), the library
+// routine beyond (a Gauss-Newton step of more than 45 degrees: rare)
+__device__ __forceinline__ void step_sincos(double x, double* s, double* c) {
+    if (fabs(x) > 0.8) { sincos(x, s, c); return; }
+    const double x2 = x * x;
+    double ps = -1.0 / 121645100408832000.0;            // 1/19!
+    ps = fma(ps, x2, 1.0 / 355687428096000.0);           // 1/17!
+    ps = fma(ps, x2, -1.0 / 1307674368000.0);            // 1/15!
+    ps = fma(ps, x2, 1.0 / 6227020800.0);                // 1/13!
+    ps = fma(ps, x2, -1.0 / 39916800.0);                 // 1/11!
+    ps = fma(ps, x2, 1.0 / 362880.0);                    // 1/9!
+    ps = fma(ps, x2, -1.0 / 5040.0);                     // 1/7!
+    ps = fma(ps, x2, 1.0 / 120.0);                       // 1/5!
+    ps = fma(ps, x2, -1.0 / 6.0);                        // 1/3!
+    *s = fma(ps * x2, x, x);
+    double pc = 1.0 / 6402373705728000.0;                // 1/18!
+    pc = fma(pc, x2, -1.0 / 20922789888000.0);           // 1/16!
+    pc = fma(pc, x2, 1.0 / 87178291200.0);               // 1/14!
+    pc = fma(pc, x2, -1.0 / 479001600.0);                // 1/12!
+    pc = fma(pc, x2, 1.0 / 3628800.0);                   // 1/10!
+    pc = fma(pc, x2, -1.0 / 40320.0);                    // 1/8!
+    pc = fma(pc, x2, 1.0 / 720.0);                       // 1/6!
+    pc = fma(pc, x2, -1.0 / 24.0);                       // 1/4!
+    pc = fma(pc, x2, 0.5);                               // 1/2!
+    *c = fma(-pc, x2, 1.0);
+}
+
+// 6x6 SPD solve, LDL^T with reciprocal pivots (no square roots); false if a pivot is not positive
 __device__ inline bool ldlt_solve6(const double* H, const double* b, double* x) {
     double L[6][6], d[6], id[6];
     for (int j = 0; j < 6; ++j) {
         double s = H[j * 6 + j];
         for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k] * d[k];
         if (!(s > 0.0)) return false;
-        d[j] = s; id[j] = 1.0 / s;
+        d[j] = s; id[j] = fast_rcp(s);
         for (int i = j + 1; i < 6; ++i) {
             double v = H[i * 6 + j];
             for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
@@ -494,84 +538,138 @@ __device__ inline bool ldlt_solve6(const double* H, const double* b, double* x) 
 #define HB_M_BITS 0x0000000b72761210ull
 __device__ __forceinline__ int hb_m_slot(int k, int l) { return (int)((HB_M_BITS >> (4 * (3 * k + l))) & 15ull); }
 __device__ __forceinline__ int hb_n_slot(int k, int j) { return (k == 0 ? 3 : k == 1 ? 8 : 12) + j; }
+// (branch-free: every lane reads the operands of all three kinds — some twenty LDS reads issued together, one wait — and
+// selects; three divergent paths with a wait each took three times as long on the single-scan loop's critical path)
 __device__ __forceinline__ double hb_entry(const double* R, const double* raw, int e) {
     const int kind = (int)((HB_KIND_BITS >> (2 * e)) & 3ull), i = (int)((HB_I_BITS >> (2 * e)) & 3ull), j = (int)((HB_J_BITS >> (2 * e)) & 3ull);
-    if (kind == 0) return raw[e];
+    const double own = raw[e];
+    const double Rj0 = R[j], Rj1 = R[3 + j], Rj2 = R[6 + j], Ri0 = R[i], Ri1 = R[3 + i], Ri2 = R[6 + i];
     double t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (kind == 1) t[k] = (raw[hb_m_slot(k, 0)] * R[j] + raw[hb_m_slot(k, 1)] * R[3 + j]) + raw[hb_m_slot(k, 2)] * R[6 + j];   // (M R)(k,j)
-        else if (kind == 2) t[k] = raw[hb_n_slot(k, j)];
-        else t[k] = raw[21 + k];
+        const double mr = (raw[hb_m_slot(k, 0)] * Rj0 + raw[hb_m_slot(k, 1)] * Rj1) + raw[hb_m_slot(k, 2)] * Rj2;   // (M R)(k,j)
+        const double nk = raw[hb_n_slot(k, j)], wk = raw[21 + k];
+        t[k] = kind == 1 ? mr : kind == 2 ? nk : wk;
     }
-    const double v = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
-    return kind == 3 ? -v : v;
-}
-__device__ void raw_to_Hb(const double* R, double* acc) {
-    double out[ACC_N];
-    for (int e = 0; e < ACC_N; ++e) out[e] = hb_entry(R, acc, e);
-    for (int e = 0; e < ACC_N; ++e) acc[e] = out[e];
+    const double v = (Ri0 * t[0] + Ri1 * t[1]) + Ri2 * t[2];
+    return kind == 0 ? own : kind == 3 ? -v : v;
 }
 
-// One Gauss-Newton step from the reduced accumulators: dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6]
-// (Exp: Rodrigues as src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad).
-__device__ void gn_step(GnState* st, const double* acc, const SolveParams& sp) {
-    if ((long long)acc[ACC_NEFF] < (long long)sp.min_effective_pts) { st->status = NDT_ERR_TOO_FEW_POINTS; st->done = 1; return; }
-    double H[36], b[6], dx[6];
-    int t = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c, ++t) { H[r * 6 + c] = acc[t]; H[c * 6 + r] = acc[t]; }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) b[r] = acc[21 + r];
-    if (!ldlt_solve6(H, b, dx)) { st->status = NDT_ERR_SINGULAR; st->done = 1; return; }
-    double nrm = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { st->dx[j] = dx[j]; nrm += dx[j] * dx[j]; }
-    nrm = sqrt(nrm);
-    double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const double th = sqrt((dx[0] * dx[0] + dx[1] * dx[1]) + dx[2] * dx[2]);
-    if (th > 1e-7) {
-        const double ith = 1.0 / th;
-        const double a0 = dx[0] * ith, a1 = dx[1] * ith, a2 = dx[2] * ith;
-        const double Km[9] = {0, -a2, a1, a2, 0, -a0, -a1, a0, 0};
-        double s, c;
-        sincos(th, &s, &c);
-        const double c1 = 1.0 - c;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double kk = (Km[3 * i] * Km[j] + Km[3 * i + 1] * Km[3 + j]) + Km[3 * i + 2] * Km[6 + j];
-                E[3 * i + j] += s * Km[3 * i + j] + c1 * kk;
-            }
+// ---- the Gauss-Newton step, on one wave.  dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6] (Exp: Rodrigues as
+// src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad).  It sits on the critical path of every iteration of the
+// single-scan loop (one dependent chain, every block waiting), so it is spread over lanes: lane i < 6 owns row i of the
+// LDL^T factorisation and of the two substitutions, lane e < 9 one entry of Exp and of the new rotation; values cross lanes
+// through v_readlane.  A third of the instructions of the one-lane form and shorter dependent chains; every form of the
+// loop (chained, two launches, batched, sharded) calls this one function, so they all take identical steps.
+__device__ __forceinline__ double bcast(double v, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+// all 64 lanes of the wave call it; hb = the 32 converted accumulators (LDS); st may be LDS or global; xch = 36 doubles of
+// LDS the wave may use (the factor's rows are transposed through it for the back substitution)
+__device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, double* xch, const SolveParams& sp) {
+    const int lane = threadIdx.x & 63;
+    if ((long long)hb[ACC_NEFF] < (long long)sp.min_effective_pts) {
+        if (lane == 0) { st->status = NDT_ERR_TOO_FEW_POINTS; st->done = 1; }
+        return;
     }
-    double Rn[9];
+    const int i = lane < 6 ? lane : 5;
+    double h[6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int c = 0; c < 6; ++c) {
+        const int r = i < c ? i : c, cc = i < c ? c : i;
+        h[c] = hb[r * 6 - (r * (r - 1)) / 2 + (cc - r)];        // packed upper triangle, row-major
+    }
+    double y = hb[21 + i];
+    double Lr[6] = {0, 0, 0, 0, 0, 0}, d[6], id[6];
+    double dmin = 1.0;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) Rn[3 * i + j] = (st->R[3 * i] * E[j] + st->R[3 * i + 1] * E[3 + j]) + st->R[3 * i + 2] * E[6 + j];
+    for (int j = 0; j < 6; ++j) {          // column j: pivot on lane j, the entries below it on lanes j + 1 ..
+        double v = h[j];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) st->R[j] = Rn[j];
+        for (int k = 0; k < j; ++k) v = fma(-Lr[k], bcast(Lr[k] * d[k], j), v);
+        const double dj = bcast(v, j);
+        dmin = (dj > 0.0 && dmin > 0.0) ? dmin : -1.0;      // (a NaN pivot fails too)
+        d[j] = dj; id[j] = fast_rcp(dj);
+        Lr[j] = v * id[j];
+    }
+    if (!(dmin > 0.0)) {                   // (uniform: every pivot is a broadcast)
+        if (lane == 0) { st->status = NDT_ERR_SINGULAR; st->done = 1; }
+        return;
+    }
+    // the factor's rows go to LDS so that lane i can read column i (L[k][i], k > i) for the back substitution
+    if (lane < 6) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) st->t[j] += dx[3 + j];
-    st->dx_norm = nrm;
+        for (int k = 0; k < 5; ++k) xch[6 * lane + k] = Lr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {          // L y = b
+        const double yk = bcast(y, k);
+        y = i > k ? fma(-Lr[k], yk, y) : y;
+    }
+    double my_id = id[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) my_id = i == c ? id[c] : my_id;
+    double x = y * my_id;                  // D z = y, then L^T x = z
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double Lc[6];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) Lc[k] = xch[6 * k + i];          // L[k][i] (used for k > i only)
+#pragma unroll
+    for (int k = 5; k >= 1; --k) {
+        const double xk = bcast(x, k);
+        x = i < k ? fma(-Lc[k], xk, x) : x;
+    }
+    const double dx0 = bcast(x, 0), dx1 = bcast(x, 1), dx2 = bcast(x, 2);
+    const double xx = x * x;               // |dx|^2 = sum over lanes 0..5 (the square root is the host's: it is only reported)
+    const double nrm2 = ((((bcast(xx, 0) + bcast(xx, 1)) + bcast(xx, 2)) + bcast(xx, 3)) + bcast(xx, 4)) + bcast(xx, 5);
+    // new rotation R Exp(dx[0:3]), Exp = I + sin(th) K + (1 - cos(th)) (a a^T - I), K = hat(a), a = dx[0:3] / th:
+    // lane e = 3 r + c computes column c of Exp and from it entry (r, c) of the product
+    const int e = lane < 9 ? lane : 8, r = e / 3, c = e - 3 * r;
+    const double th2 = (dx0 * dx0 + dx1 * dx1) + dx2 * dx2;
+    double E0 = c == 0 ? 1.0 : 0.0, E1 = c == 1 ? 1.0 : 0.0, E2 = c == 2 ? 1.0 : 0.0;      // E[m][c], m = 0, 1, 2
+    if (th2 > 1e-14) {
+        double ith = __builtin_amdgcn_rsq(th2);            // 1 / th: hardware estimate + two Newton steps
+        ith = ith * fma(-0.5 * th2, ith * ith, 1.5);
+        ith = ith * fma(-0.5 * th2, ith * ith, 1.5);
+        const double th = th2 * ith;
+        const double a0 = dx0 * ith, a1 = dx1 * ith, a2 = dx2 * ith;
+        double sn, cs;
+        step_sincos(th, &sn, &cs);
+        const double c1 = 1.0 - cs;
+        const double ac = c == 0 ? a0 : c == 1 ? a1 : a2;
+        // column c of K = hat(a): c = 0: (0, a2, -a1); c = 1: (-a2, 0, a0); c = 2: (a1, -a0, 0)
+        const double k0 = c == 1 ? -a2 : c == 2 ? a1 : 0.0, k1 = c == 0 ? a2 : c == 2 ? -a0 : 0.0, k2 = c == 0 ? -a1 : c == 1 ? a0 : 0.0;
+        E0 += fma(sn, k0, c1 * (a0 * ac - (c == 0 ? 1.0 : 0.0)));
+        E1 += fma(sn, k1, c1 * (a1 * ac - (c == 1 ? 1.0 : 0.0)));
+        E2 += fma(sn, k2, c1 * (a2 * ac - (c == 2 ? 1.0 : 0.0)));
+    }
+    const double Rn = (st->R[3 * r] * E0 + st->R[3 * r + 1] * E1) + st->R[3 * r + 2] * E2;
+    const double tn = st->t[lane >= 3 && lane < 6 ? lane - 3 : 0] + x;      // lanes 3..5 hold dx[3..5]
     const int it = st->iter + 1;
-    st->iter = it;
-    if (nrm < sp.eps) { st->converged = 1; st->done = 1; }
-    if (it >= sp.max_iterations) st->done = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();       // every lane has read the old pose before any lane writes the new one
+    if (lane < 9) st->R[lane] = Rn;
+    if (lane >= 3 && lane < 6) st->t[lane - 3] = tn;
+    if (lane < 6) st->dx[lane] = x;
+    if (lane == 0) {
+        st->dx_norm2 = nrm2;
+        st->iter = it;
+        if (nrm2 < sp.eps * sp.eps) { st->converged = 1; st->done = 1; }
+        if (it >= sp.max_iterations) st->done = 1;
+    }
 }
 
 #define RED_THREADS 1024
-// thread (row group r = tid / 32, column c = tid % 32) adds partial rows r, r+RG, ... in order; the RG sums are then
-// combined by a fixed binary tree in LDS.  Result in sm[0][*].
+// thread (row group r = tid / 32, column c = tid % 32) adds partial rows r, r+RG, ... in order into sm[r][c]; the RG sums
+// of a column are then combined by one lane in a fixed binary tree (wave0_finish).  Ends with a block barrier.
 template <int RG>
-__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], bool live) {
+__device__ __forceinline__ void row_group_sums(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], bool live) {
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     double v = 0.0;
     if (live) {
-        // rows r, r+32, ... : eight loads in flight at a time (they are L2 misses: other CUs just wrote them),
+        // rows r, r+RG, ... : eight loads in flight at a time (they are L2 misses: other CUs just wrote them),
         // added strictly in row order
         for (int i0 = r; i0 < n_partials; i0 += RG * 8) {
             double x[8];
@@ -586,17 +684,11 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
     }
     sm[r][c] = v;
     __syncthreads();
-#pragma unroll
-    for (int o = RG / 2; o >= 1; o >>= 1) {
-        if (r < o) sm[r][c] += sm[r + o][c];
-        __syncthreads();
-    }
 }
-
-// reduce_rows<32> on a 512-thread block, same bits: thread (r, c) keeps the sums of row groups r and r + 16 apart and
+// row_group_sums<32> on a 512-thread block, same bits: thread (r, c) keeps the sums of row groups r and r + 16 apart and
 // adds them as the tree's first level would (a group's running sum starts at +0 and can never become -0, so the
-// zero padding the 1024-thread form adds is immaterial).
-__device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]) {
+// zero padding the 1024-thread form adds is immaterial).  Leaves 16 sums per column: the tree goes on from its second level.
+__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]) {
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     double va = 0.0, vb = 0.0;
     for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
@@ -614,11 +706,36 @@ __device__ __forceinline__ void reduce_rows32_on512(const double* __restrict__ p
     }
     sm[r][c] = va + vb;
     __syncthreads();
+}
+// the fixed binary tree over the RG sums of column `c`: level o adds entry r + o to entry r for r < o, o = RG/2 .. 1
+template <int RG>
+__device__ __forceinline__ double column_tree(double (*sm)[ACC_N + 1], int c) {
+    double v[RG];
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) {
-        if (r < o) sm[r][c] += sm[r + o][c];
-        __syncthreads();
-    }
+    for (int r = 0; r < RG; ++r) v[r] = sm[r][c];
+#pragma unroll
+    for (int o = RG / 2; o >= 1; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < o; ++r) v[r] += v[r + o];
+    return v[0];
+}
+// The block's first wave (all 64 lanes), after the barrier that made the RG sums per column visible: column tree, the
+// raw row -> H, b at the state's pose (one lane per entry; also stored in st->acc), and the Gauss-Newton step.  Only
+// wave-level ordering in here: LDS operations of one wave execute in issue order.  sm has at least 4 rows.
+template <int RG>
+__device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* st, const SolveParams& sp, bool do_solve) {
+    const int lane = threadIdx.x & 63;
+    if (lane < ACC_N) sm[0][lane] = column_tree<RG>(sm, lane);      // a lane reads and writes its own column only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    STAMP(6);
+    double v = 0.0;
+    if (lane < ACC_N) v = hb_entry(st->R, sm[0], lane);
+    if (lane < ACC_N) { sm[1][lane] = v; st->acc[lane] = v; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    STAMP(7);
+    if (do_solve) gn_step_wave(st, sm[1], &sm[2][0], sp);      // rows 2.. are free once the tree has run (36 doubles: sm has >= 4 rows)
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
@@ -627,59 +744,34 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
     const int done = st->done;
-    reduce_rows<32>(partials, n_partials, sm, true);
+    row_group_sums<32>(partials, n_partials, sm, true);
     if (!force && done) return;
-    if (threadIdx.x < ACC_N) {          // world-frame sums -> H, b at the state's pose, one lane per entry
-        const double v = hb_entry(st->R, sm[0], threadIdx.x);
-        sm[1][threadIdx.x] = v;
-        st->acc[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (do_solve && threadIdx.x == 0) {
-        double acc[ACC_N];
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[1][j];
-        gn_step(st, acc, sp);
-    }
+    if (threadIdx.x < 64) wave0_finish<32>(sm, st, sp, do_solve != 0);
 }
 // multi-GPU form: the local sum goes to a row that RCCL all-reduces, and the step reads the reduced row
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __restrict__ partials, int n_partials, const GnState* st,
                                                              double* row_out, int force) {
     __shared__ double sm[32][ACC_N + 1];
-    reduce_rows<32>(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
-    if (threadIdx.x < ACC_N) row_out[threadIdx.x] = sm[0][threadIdx.x];
+    row_group_sums<32>(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
+    if (threadIdx.x < ACC_N) row_out[threadIdx.x] = column_tree<32>(sm, threadIdx.x);
 }
-__global__ void k_solve_only(GnState* st, const double* reduced, SolveParams sp, int do_solve, int force) {
+__global__ __launch_bounds__(64) void k_solve_only(GnState* st, const double* reduced, SolveParams sp, int do_solve, int force) {
+    __shared__ double sm[4][ACC_N + 1];
     if (!force && st->done) return;
-    if (threadIdx.x == 0) {
-        double acc[ACC_N];
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) acc[j] = reduced[j];
-        raw_to_Hb(st->R, acc);
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) st->acc[j] = acc[j];
-        if (do_solve) gn_step(st, acc, sp);
-    }
+    if (threadIdx.x < ACC_N) { sm[0][threadIdx.x] = reduced[threadIdx.x]; sm[1][threadIdx.x] = 0.0; }
+    __syncthreads();
+    wave0_finish<2>(sm, st, sp, do_solve != 0);      // (the second "group" is zero: the tree adds +0)
 }
 
 #define BRED_THREADS 256
 // batched form: one block per pair; counts the pairs that finish in *n_done
-__device__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done) {
+__device__ __forceinline__ void reduce_solve_pair(const double* partials, int rows_per_pair, GnState* st, const SolveParams& sp, int do_solve, int force, int32_t* n_done) {
     __shared__ double sm[BRED_THREADS / 32][ACC_N + 1];
-    reduce_rows<BRED_THREADS / 32>(partials, rows_per_pair, sm, true);
+    row_group_sums<BRED_THREADS / 32>(partials, rows_per_pair, sm, true);
     if (!force && st->done) return;            // (uniform over the block: nobody has written the state yet)
-    if (threadIdx.x < ACC_N) {                 // world-frame sums -> H, b at the state's pose, one lane per entry
-        const double v = hb_entry(st->R, sm[0], threadIdx.x);
-        sm[1][threadIdx.x] = v;
-        st->acc[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (do_solve && threadIdx.x == 0) {
-        double acc[ACC_N];
-#pragma unroll
-        for (int j = 0; j < ACC_N; ++j) acc[j] = sm[1][j];
-        gn_step(st, acc, sp);
-        if (st->done) atomicAdd(n_done, 1);
+    if (threadIdx.x < 64) {
+        wave0_finish<BRED_THREADS / 32>(sm, st, sp, do_solve != 0);
+        if (do_solve && threadIdx.x == 0 && st->done) atomicAdd(n_done, 1);
     }
 }
 __global__ __launch_bounds__(BRED_THREADS) void k_reduce_solve_batch(const double* __restrict__ partials, int rows_per_pair, GnState* states,
