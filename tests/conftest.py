@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("keys", "voxels", "pair", "downsample", "pcl")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("keys", "voxels", "pair", "downsample", "pcl", "config1", "yard")}
 
 
 def pose_error(T, T_ref):

@@ -208,6 +208,50 @@ def gen_pair():
     np.savez_compressed(os.path.join(HERE, "pair.npz"), **out)
 
 
+# ------------------------------------------------------------------ (vii) configs[1] at full size: 30k-pt scan vs 200k-pt map
+def gen_config1():
+    """BASELINE.json configs[1] as synth.make_config(1) generates it (the inputs are regenerated by the tests from the
+    seed; a checksum guards against drift): every voxel's key and count, the regularised information matrix of the
+    first 1500 valid voxels (np.linalg.eigh), H / b / chi2 / n_eff at the guess for NEARBY7, and the same sums over
+    the two halves of the source (what two ranks of the sharded mode contribute)."""
+    c = synth.make_config(1)
+    m, s, guess = c["map"], c["scan"], c["guess"]
+    vox = build_map(m, quantize=True)
+    keys = np.array(sorted(vox.keys()), np.int32)
+    k3 = target_keys(m, 1.0, 0)
+    uk, cnt = np.unique(k3, axis=0, return_counts=True)
+    assert np.array_equal(uk.astype(np.int32), keys)
+    valid = np.array([vox[tuple(k)][2] for k in keys], np.uint8)
+    sel = np.flatnonzero(valid)[:1500]
+    info = np.stack([vox[tuple(keys[i])][1] for i in sel])
+    off = np.stack([vox[tuple(keys[i])][0] for i in sel])
+    out = {"keys": keys, "counts": cnt.astype(np.int32), "valid": valid, "info_idx": sel.astype(np.int32), "info": info, "offset": off,
+           "input_checksum": np.array([float(m.astype(np.float64).sum()), float(s.astype(np.float64).sum()), float(guess.sum())])}
+    H, b, c2, ne, _, masks = evaluate(vox, s, guess, 7)
+    out.update(H=H, b=b, chi2=c2, neff=ne, masks=masks)
+    h = len(s) // 2
+    for tag, part in (("a", s[:h]), ("b", s[h:])):
+        Hs, bs, c2s, nes, _, _ = evaluate(vox, part, guess, 7)
+        out.update({f"H_{tag}": Hs, f"b_{tag}": bs, f"chi2_{tag}": c2s, f"neff_{tag}": nes})
+    np.savez_compressed(os.path.join(HERE, "config1.npz"), **out)
+
+
+def gen_yard():
+    """The 200k-point yard map of synth.make_config(2, small=True) (thousands of voxels): every key and count, and the
+    regularised information matrix (np.linalg.eigh) + mean offset of 1500 valid voxels spread over the map."""
+    m = synth.make_config(2, small=True)["map"]
+    vox = build_map(m, quantize=True)
+    keys = np.array(sorted(vox.keys()), np.int32)
+    uk, cnt = np.unique(target_keys(m, 1.0, 0), axis=0, return_counts=True)
+    assert np.array_equal(uk.astype(np.int32), keys)
+    valid = np.array([vox[tuple(k)][2] for k in keys], np.uint8)
+    vi = np.flatnonzero(valid)
+    sel = vi[np.linspace(0, len(vi) - 1, 1500).astype(int)]
+    np.savez_compressed(os.path.join(HERE, "yard.npz"), keys=keys, counts=cnt.astype(np.int32), valid=valid, info_idx=sel.astype(np.int32),
+                        info=np.stack([vox[tuple(keys[i])][1] for i in sel]), offset=np.stack([vox[tuple(keys[i])][0] for i in sel]),
+                        input_checksum=np.array([float(m.astype(np.float64).sum())]))
+
+
 # ------------------------------------------------------------------ (vi) VoxelGrid centroid downsample (§8(f) N1)
 def gen_downsample():
     rng = np.random.Generator(np.random.PCG64(13))
@@ -357,9 +401,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pcl":
         gen_pcl()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":
+        gen_config1()
+        gen_yard()
+        sys.exit(0)
     gen_downsample()
     gen_keys()
     gen_voxels()
     gen_pair()
     gen_pcl()
+    gen_config1()
+    gen_yard()
     print("golden vectors written to", HERE)

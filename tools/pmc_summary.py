@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 def short(n): return n.split("(")[0].replace("void ", "")
 out_txt, result = [], {"_how": __doc__}
-for mode in ("online", "large", "build"):
+for mode in ("online", "large", "dense", "build"):
     metaf = f"gpurun_out/prof_meta_{mode}.json"
     if not os.path.exists(metaf):
         continue

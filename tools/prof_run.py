@@ -2,6 +2,7 @@
    prof_run.py online N B : N aligns of configs[2] scan0 (k_residual_chain x iterations + one k_reduce_solve each), N x 2
                             single passes (k_residual), B batched aligns of one launch lane of bench.py's default batch
    prof_run.py large N    : N x 2 single passes + 1 align of the 2M-pt source against the 20M-pt / >500k-voxel map
+   prof_run.py dense N    : the same passes on the 2M-pt source against the configs[2] voxel map replicated 10 x 10 (2.2M voxels)
    prof_run.py build N    : N rebuilds of the 2M-pt map from HBM-resident input + N keyframe merges of the resident source
 Writes gpurun_out/prof_meta_<mode>.json: points per launch of every kernel the summary reports on."""
 import json, os, sys
@@ -39,6 +40,25 @@ elif mode == "large":
     for _ in range(n_rep):
         ndt.eval(lm["guess"]); ndt.eval(r["T"])
     meta["k_residual<7>@large_map"] = {"match": "k_residual<7, false, true>", "points_per_launch": ndt.source_size()}
+    print("done", r["iterations"], ndt.num_voxels())
+elif mode == "dense":
+    import numpy as np
+    from lio_slam_amd import synth
+    w = bench.load_workload(2, 0, 1, None, False)
+    ndt = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
+    ndt.set_target(w["map"]); ndt.load_map(bench.replicate_map_blob(ndt.save_map(), 10, 10, 300))
+    T0 = w["T0"]; sub = w["scan0"][::6]
+    parts = []
+    for ix in range(10):
+        for iy in range(10):
+            wp = synth.transform(T0, sub) + np.array([300.0 * ix, 300.0 * iy, 0.0], np.float32)
+            parts.append(((wp.astype(np.float64) - T0[:3, 3]) @ T0[:3, :3]).astype(np.float32))
+    ndt.set_source(np.concatenate(parts))
+    gd = T0 @ synth.se3([6e-6, -5e-6, 6e-6], [0.07, -0.06, 0.03])
+    r = ndt.align(gd)
+    for _ in range(n_rep):
+        ndt.eval(gd); ndt.eval(r["T"])
+    meta["k_residual<7>@large_dense"] = {"match": "k_residual<7, false, true>", "points_per_launch": ndt.source_size()}
     print("done", r["iterations"], ndt.num_voxels())
 elif mode == "build":
     w = bench.load_workload(2, 0, 1, None, False)
