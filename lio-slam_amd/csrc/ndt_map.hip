@@ -761,7 +761,7 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act)
     const unsigned long long am = __ballot(act);
     if (!am) return;
     const int lane = threadIdx.x & 63;
-    const unsigned d0 = (unsigned)__shfl((int)d, __ffsll((long long)am) - 1);
+    const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);      // any lane's digit will do for the test below
     if (!__any(act && d != d0)) {          // all active lanes share one digit (the usual case for the higher digits): one add
         if (lane == __ffsll((long long)am) - 1) atomicAdd(&h[d0], (uint32_t)__popcll(am));
         return;
@@ -845,8 +845,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
         const bool act = base + (size_t)r * 64 < n;
         const unsigned d = (e[r].x >> shift) & 255u;
         const unsigned long long am = __ballot(act);
-        const int first = am ? __ffsll((long long)am) - 1 : 0;
-        const unsigned d0 = (unsigned)__shfl((int)d, first);
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         unsigned long long m;
         if (!__any(act && d != d0)) m = am;                       // one digit in the whole wave: the usual case for the higher digits
         else m = same_digit_lanes(d, act);
@@ -988,7 +987,9 @@ __global__ __launch_bounds__(SH_THREADS) void k_seg_heads32(const uint4* elems, 
 }
 
 // what the segment kernels derive from the segment count, each for itself (no planning kernel in between)
-__device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 24; }   // 64 lanes per segment, else 8
+// 64 lanes per segment when voxels hold many points, else 8 (eight segments per wave side by side: at 25 points per voxel
+// the 20 M-point map's 815 k segments took 0.99 ms one wave each, the per-segment chain of dependent loads being the cost)
+__device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 64; }
 __device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? 2048u : 256u; }   // <= 32 trips of a group
 
 // end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
