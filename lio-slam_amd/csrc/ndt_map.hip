@@ -19,16 +19,21 @@
 
 // ------------------------------------------------------------------ table init / alloc
 
-__global__ void k_init_slots(VoxSlot* s, int64_t* keys, int32_t* counts, size_t cap) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap + 4) keys[i] = NDT_KEY_EMPTY;
-    if (i >= cap) return;
-    VoxSlot v = {};
-#pragma unroll
-    for (int j = 0; j < 6; ++j) v.link[j] = NDT_LINK_NONE;
-    s[i] = v;
-    counts[i] = 0;
+// Empty table: zero payloads, unset links, empty keys, zero counts.  Neighbouring lanes write neighbouring 16-byte
+// pieces (a thread per slot wrote four pieces 64 bytes apart: 1.5 TB/s on a 268 MB table).
+static_assert(offsetof(VoxSlot, link) == 40, "k_init_slots writes the links as the last six words of the slot");
+__global__ __launch_bounds__(256) void k_init_slots(VoxSlot* s, int64_t* keys, int32_t* counts, size_t cap) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int4* q = (int4*)s;
+    const int none = (int)NDT_LINK_NONE;
+    for (size_t i = t0; i < cap * 4; i += stride) {
+        const int piece = (int)(i & 3);
+        q[i] = piece == 3 ? make_int4(none, none, none, none) : piece == 2 ? make_int4(0, 0, none, none) : make_int4(0, 0, 0, 0);
+    }
+    for (size_t i = t0; i < cap + 4; i += stride) keys[i] = NDT_KEY_EMPTY;
+    for (size_t i = t0; i < cap; i += stride) counts[i] = 0;
 }
+static unsigned init_slots_grid(size_t cap) { return (unsigned)std::min<size_t>(4096, (cap * 4 + 255) / 256); }
 
 hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     hipError_t e;
@@ -41,7 +46,7 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     if ((e = hipMemsetAsync(m.d_n_vox, 0, 256, s)) != hipSuccess) return e;
     m.cap = cap;
     m.n_vox = 0; m.n_entries = 0;
-    k_init_slots<<<(unsigned)((cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.counts, cap);
+    k_init_slots<<<init_slots_grid(cap), 256, 0, s>>>(m.slots, m.keys, m.counts, cap);
     return hipGetLastError();
 }
 // empties the table in place (keeps the allocation: a rebuild of a same-sized map allocates nothing)
@@ -50,7 +55,7 @@ hipError_t map_clear(VoxelMap& m, hipStream_t s) {
     hipError_t e = hipMemsetAsync(m.d_n_vox, 0, 256, s);
     if (e != hipSuccess) return e;
     m.n_vox = 0; m.n_entries = 0;
-    k_init_slots<<<(unsigned)((m.cap + 4 + 255) / 256), 256, 0, s>>>(m.slots, m.keys, m.counts, m.cap);
+    k_init_slots<<<init_slots_grid(m.cap), 256, 0, s>>>(m.slots, m.keys, m.counts, m.cap);
     return hipGetLastError();
 }
 void map_free(VoxelMap& m) {
@@ -723,6 +728,7 @@ static int bits_for(int64_t range) { int b = 0; while ((1ll << b) < range) ++b; 
 #define PL_SORT_ERR 13   // a one-sweep pass gave up waiting for a predecessor tile (never seen; the host then sorts with the three-kernel passes)
 #define PL_ABORT1 42     // the batch's voxels may not fit the table: the insert stages did nothing, the host grows the table and re-runs them
 #define PL_ABORT2 43     // the ghost cells may not fit: the ghost stage did nothing, the host grows the table and re-runs it
+#define PL_HUGECOUNT 44  // segments too long for one wave (summed by a block each)
 #define PL_NEW_VOX 45    // voxels that got their first points (= length of the fresh list)
 #define PL_NEW_ENT 46    // table entries created for voxels
 #define PL_NEW_GHOST 47  // table entries created for ghost cells
@@ -819,16 +825,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char
 #define OS_PRE (2ull << 62)
 #define OS_VAL ((1ull << 62) - 1ull)
 #define OS_SPIN_LIMIT (1 << 22)
+// Diagnostic build only (-DNDT_STAMPS, tools/exp_sort_stamps.py): the device-wide clock at the phase boundaries of every
+// tile of a pass.  The product library is built without it.
+#ifdef NDT_STAMPS
+#define OS_STAMP_TILES 8192
+__device__ unsigned long long g_os_stamps[OS_STAMP_TILES][8];
+#define OS_STAMP(k) do { if (threadIdx.x == 0 && tile < OS_STAMP_TILES) { g_os_stamps[tile][k] = wall_clock64(); if (k == 1) g_os_stamps[tile][0] = t_entry; } } while (0)
+extern "C" int ndt_debug_os_stamps(unsigned long long* out, int tiles) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_stamps), (size_t)tiles * 64); }
+#else
+#define OS_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
                                                            const uint32_t* __restrict__ ghist, unsigned long long* status, uint32_t* ticket, int32_t* err) {
     __shared__ uint32_t s_tile;
     __shared__ uint32_t wcnt[4][256];      // per wave: running count of each digit, then the wave's first output position of it
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef NDT_STAMPS
+    const unsigned long long t_entry = wall_clock64();
+#endif
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int j = 0; j < 4; ++j) wcnt[j][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
+    OS_STAMP(1);
     // element order inside a tile: (wave, round, lane) — every wave owns 1024 consecutive elements, so ranking needs no
     // block barrier per round
     const size_t base = (size_t)tile * OS_TILE + (size_t)w * (64 * OS_ITEMS) + lane;
@@ -856,6 +876,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    OS_STAMP(2);
     // this thread owns digit threadIdx.x: global base of the digit + what the earlier tiles hold of it
     const uint32_t excl = block_exclusive_scan_256(ghist[threadIdx.x], nullptr);
     const uint32_t c0 = wcnt[0][threadIdx.x], c1 = wcnt[1][threadIdx.x], c2 = wcnt[2][threadIdx.x], c3 = wcnt[3][threadIdx.x];
@@ -891,7 +912,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
         }
         __hip_atomic_store(mine, OS_PRE | (before + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    OS_STAMP(3);
     __syncthreads();                       // (block_exclusive_scan_256's shared words and every wave's counts are read)
+    OS_STAMP(4);
     const uint32_t p0 = excl + (uint32_t)before;
     wcnt[0][threadIdx.x] = p0; wcnt[1][threadIdx.x] = p0 + c0; wcnt[2][threadIdx.x] = p0 + c0 + c1; wcnt[3][threadIdx.x] = p0 + c0 + c1 + c2;
     __syncthreads();
@@ -902,6 +925,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
             if (pos < n) out[pos] = e[r];        // (always, unless a wait ran out)
         }
     }
+    OS_STAMP(5);
 }
 
 // the three-kernel form of a pass (histograms per tile, exclusive scan, scatter): the fallback of k_onesweep32
@@ -994,9 +1018,12 @@ __device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { r
 
 // end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
 #define SEG_NONE 0xFFFFFFFFu
-__global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t n_valid, const uint32_t* seg_pos, const int32_t* plan, uint32_t* seg_end,
-                                                   uint32_t* big_pos, uint32_t* big_list, uint32_t* big_count) {
+#define HUGE_SEG 4096u        // 8-lane mode: up to this many points a big segment is summed by one wave (16 trips), beyond it by a block
+__global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t n_valid, const uint32_t* seg_pos, int32_t* plan, uint32_t* seg_end,
+                                                   uint32_t* big_pos, uint32_t* big_list, uint32_t list_cap, uint32_t* big_count) {
     const uint32_t nseg = (uint32_t)plan[PL_NSEG], big = seg_big(nseg, n_valid);
+    // (64-lane mode: everything above 2048 points goes to a block: a lone wave's 16 trips cost more than the block's barrier)
+    const uint32_t huge = seg_wide(nseg, n_valid) ? big : HUGE_SEG;
     const uint32_t* keys = (const uint32_t*)elems;
     const int lane = threadIdx.x & 63, l = threadIdx.x & 7, gsh = lane & ~7;
     const uint32_t groups = gridDim.x * 32u;
@@ -1025,7 +1052,9 @@ __global__ __launch_bounds__(256) void k_seg_ends32(const uint4* elems, uint32_t
             const uint32_t e = (uint32_t)lo + 1u;
             seg_end[g] = e;
             uint32_t pos = SEG_NONE;
-            if (e - s > big) { pos = atomicAdd(big_count, 1u); big_list[pos] = g; }
+            // big segments: listed from the front; those beyond one wave's reach from the back of the same array
+            if (e - s > huge) { pos = atomicAdd((uint32_t*)&plan[PL_HUGECOUNT], 1u); big_list[list_cap - 1u - pos] = g; }
+            else if (e - s > big) { pos = atomicAdd(big_count, 1u); big_list[pos] = g; }
             big_pos[g] = pos;
         }
     }
@@ -1040,13 +1069,50 @@ __device__ inline void sortkey32_origin(uint32_t sk, const SortKeyMap& km, doubl
     for (int j = 0; j < 3; ++j) org[j] = (double)c[j] * res;
 }
 
-// nine sums of one big segment per block (blocks stride over the list)
-__global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, const uint32_t* big_count, const uint4* elems, const uint32_t* seg_pos,
-                                                            const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, double* sums) {
+// nine sums of every big segment: one wave per segment up to HUGE_SEG points (waves stride over the front list), one
+// block per longer segment (blocks stride over the back list).  A block per segment for everything above 256 points took
+// 0.37 ms on the 20 M-point map, whose voxels hold 25 points on average and a few hundred near the sensor tracks.
+__global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count, const int32_t* plan,
+                                                            const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg,
+                                                            double* sums) {
     __shared__ double sm[BIG_THREADS / 64][9];
-    const uint32_t n_big = *big_count;
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {       // (uniform over the block)
+    const uint32_t n_big = *big_count, n_huge = (uint32_t)plan[PL_HUGECOUNT];
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * (BIG_THREADS / 64);
+    for (uint32_t b = blockIdx.x * (BIG_THREADS / 64) + (threadIdx.x >> 6); b < n_big; b += n_waves) {      // (uniform over the wave)
         const uint32_t g = big_list[b];
+        const uint32_t s = seg_pos[g], e = seg_end[g];
+        int64_t key;
+        double o[3];
+        sortkey32_origin(elems[s].x, km, cfg.kp.res_d, &key, o);
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i0 = s + lane; i0 < e; i0 += 4 * 64) {       // four elements in flight per lane, added in index order
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * 64;
+                v[u] = i < e ? elems[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * 64 >= e) break;
+                const double d0 = (double)__uint_as_float(v[u].y) - o[0], d1 = (double)__uint_as_float(v[u].z) - o[1], d2 = (double)__uint_as_float(v[u].w) - o[2];
+                a[0] += d0; a[1] += d1; a[2] += d2;
+                a[3] += d0 * d0; a[4] += d0 * d1; a[5] += d0 * d2;
+                a[6] += d1 * d1; a[7] += d1 * d2; a[8] += d2 * d2;
+            }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o2);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sums[(size_t)g * 9 + j] = a[j];
+        }
+    }
+    for (uint32_t b = blockIdx.x; b < n_huge; b += gridDim.x) {       // (uniform over the block)
+        const uint32_t g = big_list[list_cap - 1u - b];
         const uint32_t s = seg_pos[g], e = seg_end[g];
         int64_t key;
         double o[3];
@@ -1072,7 +1138,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_
         for (int o2 = 32; o2 >= 1; o2 >>= 1)
 #pragma unroll
             for (int j = 0; j < 9; ++j) a[j] += __shfl_xor(a[j], o2);
-        if ((threadIdx.x & 63) == 0) {
+        if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) sm[threadIdx.x >> 6][j] = a[j];
         }
@@ -1192,7 +1258,7 @@ __device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, i
 // batch whether the table has room (n_entries: the host's exact count) and leaves the verdict in plan[PL_ABORT1].
 __global__ __launch_bounds__(256) void k_merge_finalize32(const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end, int32_t* plan, SortKeyMap km,
                                                           MapBuildCfg cfg, const double* sums, VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean,
-                                                          double* cov, uint64_t cap, uint64_t n_entries, uint32_t* fresh_list) {
+                                                          double* cov, uint64_t cap, uint64_t n_entries, uint32_t* fresh_list, uint32_t* slot_of) {
     const uint32_t nseg = (uint32_t)plan[PL_NSEG];
     const bool abort1 = (n_entries + nseg) * 2 > cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) plan[PL_ABORT1] = abort1 ? 1 : 0;
@@ -1213,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_merge_finalize32(const uint4* elems, co
             int32_t ntot;
             const uint32_t slot = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, cap - 1, &fe, &fv, mu, cv, &ntot);
             finalize_slot(&slots[slot], ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+            slot_of[g] = slot;                                   // for the ghost stage (the sums kernels are done with this array)
             n_new_ent += fe ? 1u : 0u;
         }
         const unsigned long long b = __ballot(fv);               // one returning atomic per wave
@@ -1235,9 +1302,11 @@ struct SegKeys {
     const int32_t* d_count;                                 // device word: number of items
     const uint32_t* list;                                   // item i is voxel list[i] of the batch (nullptr: voxel i)
     const uint32_t* fresh_flag;                             // nullptr, or per voxel: 0 = skip (it had points before)
+    const uint32_t* slot_of;                                // nullptr, or per voxel: its slot in the table (saves the look-up)
 };
-__device__ inline bool seg_item(const SegKeys& K, uint32_t i, int64_t* key) {
+__device__ inline bool seg_item(const SegKeys& K, uint32_t i, int64_t* key, uint32_t* slot) {
     const uint32_t g = K.list ? K.list[i] : i;
+    *slot = K.slot_of ? K.slot_of[g] : NDT_LINK_NONE;
     if (K.fresh_flag && !K.fresh_flag[g]) return false;
     if (K.plain) *key = K.plain[g];
     else if (K.elems) *key = sortkey_to_packed((uint64_t)K.elems[K.seg_pos[g]].x, K.km);
@@ -1263,14 +1332,18 @@ __global__ __launch_bounds__(256) void k_ghost_link(SegKeys K, const int32_t* d_
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)n_items * 8; t += (uint64_t)gridDim.x * blockDim.x) {
         const int d = (int)(t & 7);
         int64_t key, nk;
-        if (d >= 6 || !seg_item(K, (uint32_t)(t >> 3), &key)) continue;
-        const uint32_t own = table_find(keys, mask, key);
+        uint32_t own;
+        if (d >= 6 || !seg_item(K, (uint32_t)(t >> 3), &key, &own)) continue;
+        if (own == NDT_LINK_NONE) own = table_find(keys, mask, key);
         if (own == NDT_LINK_NONE || !neighbour_key(key, d, &nk)) continue;
         uint64_t slot = ndt_hash_key(nk) & mask;
         for (;;) {
-            const unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)nk);
-            if ((int64_t)prev == NDT_KEY_EMPTY) { ++inserted; if (slot < 4) keys[mask + 1 + slot] = nk; break; }   // the slot is zeroed: a ghost
-            if ((int64_t)prev == nk) break;
+            // keys are never removed: a plain read that shows a key is final; only an empty slot needs the atomic
+            int64_t prev = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == NDT_KEY_EMPTY)
+                prev = (int64_t)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)nk);
+            if (prev == NDT_KEY_EMPTY) { ++inserted; if (slot < 4) keys[mask + 1 + slot] = nk; break; }   // the slot is zeroed: a ghost
+            if (prev == nk) break;
             slot = (slot + 1) & mask;
         }
         slots[own].link[d] = (uint32_t)slot;
@@ -1309,7 +1382,9 @@ static int ghost_stage(VoxelMap& m, MapWork& w, const SegKeys& K, uint32_t items
     if (pw->abort2) {      // the voxels are in, their ghosts were not attempted: make room (all links are rebuilt), then link
         rc = map_reserve(m, (size_t)m.n_entries + 6 * (size_t)pw->new_vox, s, err);
         if (rc != NDT_OK) return rc;
-        k_ghost_link<<<nb, 256, 0, s>>>(K, plan + new_vox_word, plan + new_ent_word, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)(m.n_entries - pw->new_ent), plan);
+        SegKeys K2 = K;
+        K2.slot_of = nullptr;              // the table was rebuilt: the recorded slots are stale, look the voxels up
+        k_ghost_link<<<nb, 256, 0, s>>>(K2, plan + new_vox_word, plan + new_ent_word, m.keys, m.slots, (uint64_t)m.cap, (uint64_t)(m.n_entries - pw->new_ent), plan);
         HIP_TRY(hipGetLastError());
         rc = read_plan(w, new_vox_word, new_ent_word, pw, s, err);
         if (rc != NDT_OK) return rc;
@@ -1585,15 +1660,15 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     for (int attempt = 0;; ++attempt) {
         if (attempt == 0 || pw.sort_err) {
             k_seg_heads32<<<nb_heads, SH_THREADS, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] starts at zero
-            k_seg_ends32<<<nb_seg8, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), big_count);
-            k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), big_count, ea, seg_pos, seg_end, box.km, cfg, sums);
+            k_seg_ends32<<<nb_seg8, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count);
+            k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, seg_pos, seg_end, box.km, cfg, sums);
             k_segment_sums32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, seg_end, plan, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
         }
         k_merge_finalize32<<<nb_seg1, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, sums, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)m.cap,
-                                                   (uint64_t)m.n_entries, fresh_list);
+                                                   (uint64_t)m.n_entries, fresh_list, w.big_pos.as<uint32_t>());
         HIP_TRY(hipGetLastError());
         SegKeys K{};
-        K.elems = ea; K.seg_pos = seg_pos; K.km = box.km; K.d_count = plan + PL_NEW_VOX; K.list = fresh_list;
+        K.elems = ea; K.seg_pos = seg_pos; K.km = box.km; K.d_count = plan + PL_NEW_VOX; K.list = fresh_list; K.slot_of = w.big_pos.as<uint32_t>();
         rc = ghost_stage(m, w, K, (uint32_t)nseg_ub, PL_NEW_VOX, PL_NEW_ENT, &pw, s, err);
         if (rc != NDT_OK) return rc;
         if (pw.sort_err) {

@@ -3,6 +3,7 @@
                             single passes (k_residual), B batched aligns of one launch lane of bench.py's default batch
    prof_run.py large N    : N x 2 single passes + 1 align of the 2M-pt source against the 20M-pt / >500k-voxel map
    prof_run.py dense N    : the same passes on the 2M-pt source against the configs[2] voxel map replicated 10 x 10 (2.2M voxels)
+   prof_run.py buildlarge N : N rebuilds of the 20M-pt map from HBM-resident input
    prof_run.py build N    : N rebuilds of the 2M-pt map from HBM-resident input + N keyframe merges of the resident source
 Writes gpurun_out/prof_meta_<mode>.json: points per launch of every kernel the summary reports on."""
 import json, os, sys
@@ -70,6 +71,14 @@ elif mode == "build":
     for _ in range(n_rep):
         ndt.add_target_from_source(w["T0"]); ndt.synchronize()
     meta["_build"] = {"map_points": len(w["map"]), "keyframe_points": ndt.source_size(), "rebuilds": n_rep, "merges": n_rep}
+    print("done", ndt.num_voxels())
+elif mode == "buildlarge":
+    lm = bench.large_map_workload()
+    ndt = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
+    d = bench.DeviceCloud(lm["map"])
+    for _ in range(n_rep):
+        ndt.set_target(d.view()); ndt.synchronize()
+    meta["_buildlarge"] = {"map_points": len(lm["map"]), "rebuilds": n_rep, "voxels": ndt.num_voxels(), "radix_passes": ndt.last_radix_passes()}
     print("done", ndt.num_voxels())
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(meta, open(f"gpurun_out/prof_meta_{mode}.json", "w"))
