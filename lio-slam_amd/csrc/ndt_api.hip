@@ -71,6 +71,7 @@ struct ndt_handle {
     unsigned char* static_scratch = nullptr;   // this device's copy of g_static_scratch (ndt_align_static), resolved at ndt_create
     bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
+    GnState* h_state_dev = nullptr;   // the same memory as the device addresses it (the last kernel of a chained loop writes the result there)
     std::string err;
     int last_radix_passes = 0;
     int use_links = 1;           // NEARBY7 through the slots' neighbour links (NDT_NO_LINKS=1: seven hashed probes)
@@ -194,6 +195,9 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
         ndt_destroy(h);
         return nullptr;
     }
+    // optional (NDT_NO_MIRROR=1 switches it off): without it the loop copies the state back as before
+    if (getenv("NDT_NO_MIRROR") || hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess) h->h_state_dev = nullptr;
+    (void)hipGetLastError();
     return h;
 }
 
@@ -409,7 +413,7 @@ static int queue_pass(ndt_handle* h, const SourceView& src, int grid, double* ro
         if (rc != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
         launch_solve_only(st, recv, sp, do_solve, force, h->stream);
     } else {
-        launch_reduce_solve(rows, grid, st, sp, do_solve, force, h->stream);
+        launch_reduce_solve(rows, grid, st, sp, do_solve, force, nullptr, h->stream);
     }
     H_TRY(hipGetLastError());
     return NDT_OK;
@@ -497,7 +501,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
                 cur ^= 1;               // the launch published the state it used in the other buffer
                 rcur ^= 1;              // rows[rcur ^ 1] = the rows just written
             }
-            launch_reduce_solve(B.rows[rcur ^ 1], grid, B.st[cur], sp, 1, 0, h->stream);
+            launch_reduce_solve(B.rows[rcur ^ 1], grid, B.st[cur], sp, 1, 0, h->h_state_dev, h->stream);
             H_TRY(hipGetLastError());
         } else if (chained_comm) {
             // sharded source: launch i takes the step from the all-reduced row of launch i - 1 in its prologue (one "row" to sum),
@@ -518,7 +522,8 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
                 if ((rc = queue_pass(h, src, grid, B.rows[0], B.st[cur], 1, 0, nullptr, nullptr)) != NDT_OK) return rc;
         }
         queued += m;
-        H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+        // (the chained loop's last kernel has written the state into the pinned buffer itself: one command fewer to wait for)
+        if (!(chained && h->h_state_dev)) H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
         H_TRY(hipStreamSynchronize(h->stream));
         if (h->h_state->done) break;
     }

@@ -738,15 +738,26 @@ __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* s
     if (do_solve) gn_step_wave(st, sm[1], &sm[2][0], sp);      // rows 2.. are free once the tree has run (36 doubles: sm has >= 4 rows)
 }
 
+// The first wave leaves a copy of the state in `mirror` (pinned host memory the device can write; nullptr: no copy), so
+// the host reads the result after its stream wait without a copy command in between.
+static_assert(sizeof(GnState) % 8 == 0, "mirror_state copies 8-byte words");
+__device__ __forceinline__ void mirror_state(const GnState* st, GnState* mirror) {
+    if (!mirror) return;
+    __threadfence();                          // the lanes' stores to *st are done before other lanes read them back
+    const unsigned long long* s = (const unsigned long long*)st;
+    unsigned long long* d = (unsigned long long*)mirror;
+    for (int i = threadIdx.x & 63; i < (int)(sizeof(GnState) / 8); i += 64) d[i] = s[i];
+}
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
-                                                              SolveParams sp, int do_solve, int force) {
+                                                              SolveParams sp, int do_solve, int force, GnState* mirror) {
     __shared__ double sm[32][ACC_N + 1];
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
     const int done = st->done;
     row_group_sums<32>(partials, n_partials, sm, true);
-    if (!force && done) return;
-    if (threadIdx.x < 64) wave0_finish<32>(sm, st, sp, do_solve != 0);
+    if (threadIdx.x >= 64) return;
+    if (force || !done) wave0_finish<32>(sm, st, sp, do_solve != 0);
+    mirror_state(st, mirror);
 }
 // multi-GPU form: the local sum goes to a row that RCCL all-reduces, and the step reads the reduced row
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __restrict__ partials, int n_partials, const GnState* st,
@@ -795,8 +806,9 @@ void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnStat
                                int do_solve, int force, int32_t* n_done, hipStream_t s) {
     k_reduce_solve_batch<<<n_pairs, BRED_THREADS, 0, s>>>(partials, rows_per_pair, states, sp, do_solve, force, n_done);
 }
-void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, hipStream_t s) {
-    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force);
+void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, GnState* mirror,
+                         hipStream_t s) {
+    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force, mirror);
 }
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s) {
     k_reduce_rows<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, row_out, force);
