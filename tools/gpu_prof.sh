@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools/gpu_prof.sh <tag> [online|large|build ...]   (run on the GPU box via gpurun); writes gpurun_out/<tag>_<mode>_*
+# usage: tools/gpu_prof.sh <tag> [online|large|dense|build|buildlarge ...]   (run on the GPU box via gpurun); writes gpurun_out/<tag>_<mode>_*
 # One rocprofv3 run per counter group (no pass mixes --pmc with a trace), each under its own time limit.
 set -o pipefail
 tag=$1; shift
-modes=${@:-online large dense build}
+modes=${@:-online large dense build buildlarge}
 export TMPDIR=/tmp
 for mode in $modes; do
   case $mode in
@@ -11,6 +11,7 @@ for mode in $modes; do
     large)  args="large 10";     pargs="large 3";;
     dense)  args="dense 10";     pargs="dense 3";;
     build)  args="build 5";      pargs="build 2";;
+    buildlarge) args="buildlarge 4"; pargs="buildlarge 2";;
   esac
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${mode}_trace -- python3 tools/prof_run.py $args > gpurun_out/${tag}_${mode}_trace.log 2>&1 || { echo "trace $mode failed"; tail -5 gpurun_out/${tag}_${mode}_trace.log; exit 1; }
   i=0

@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 def short(n): return n.split("(")[0].replace("void ", "")
 out_txt, result = [], {"_how": __doc__}
-for mode in ("online", "large", "dense", "build"):
+for mode in ("online", "large", "dense", "build", "buildlarge"):
     metaf = f"gpurun_out/prof_meta_{mode}.json"
     if not os.path.exists(metaf):
         continue
@@ -28,7 +28,7 @@ for mode in ("online", "large", "dense", "build"):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out_txt.append(f"## {mode}: PMC per-launch means")
     for k in sorted(acc):
-        if mode != "build" and not ("k_residual" in k or "k_reduce" in k):
+        if not mode.startswith("build") and not ("k_residual" in k or "k_reduce" in k):
             continue
         out_txt.append("== " + k)
         for c, v in sorted(acc[k].items()):
@@ -56,12 +56,12 @@ for mode in ("online", "large", "dense", "build"):
         if hit is not None and miss is not None and hit + miss > 0:
             e["l2_hit_rate"] = hit / (hit + miss)
         result[key] = e
-    if mode == "build":       # whole-build traffic: sum over all kernels of a rebuild / a merge is left to the reader of the txt
+    if mode.startswith("build"):       # whole-build traffic: sum over all kernels of a rebuild / a merge is left to the reader of the txt
         tot = collections.defaultdict(float)
         for k in acc:
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot[c] += sum(acc[k].get(c, []))
-        result["build_traffic_total_kb"] = dict(tot)
+        result[f"{mode}_traffic_total_kb"] = dict(tot)
 open("profiles/r02_pmc_summary.txt", "w").write("\n".join(out_txt) + "\n")
 json.dump(result, open("profiles/pmc_r02.json", "w"), indent=1)
 print("\n".join(out_txt[:60]))
