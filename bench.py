@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--keyframe-every", type=int, default=10, help="online mode: every k-th frame is merged into the map")
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="scan-to-map pairs aligned together per step (replay section)")
     ap.add_argument("--mode", choices=["online", "sharded"], default="online")
+    ap.add_argument("--comm", choices=["p2p", "rccl"], default="p2p", help="sharded mode's all-reduce: peer stores over xGMI (default) or RCCL")
     ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the oracle accuracy gate")
     ap.add_argument("--no-extras", action="store_true", help="skip the replay / large-map / PCL-mode sections")
@@ -484,11 +485,29 @@ def main():
         build_rl = build_roofline(n_map, n_vox, rb_passes, rb_ms); del big_map
         lo, hi = shard_range(len(scan_all), rank, world)
         ranks_seen = 1
+        comm_kind = None
         if use_dist:
-            with stdout_to_stderr():                             # RCCL prints its version banner on stdout
-                ids = [la.NDT.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                ndt.comm_init(rank, world, ids[0])
+            import torch
+            if a.comm == "p2p":
+                # peer exchange: every rank's mailbox handle to every rank (gloo), peers opened over HIP IPC; all ranks fall
+                # back to RCCL together if any of them cannot open a peer
+                handles = [None] * world
+                dist.all_gather_object(handles, ndt.comm_p2p_export())
+                try:
+                    ndt.comm_p2p_init(rank, world, handles); ok = 1
+                except la.NdtError as e:
+                    print(f"[bench] rank {rank}: peer exchange unavailable ({e}); RCCL instead", file=sys.stderr); ok = 0
+                t_ok = torch.tensor([ok]); dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                if int(t_ok.item()) == 1:
+                    comm_kind = "p2p"
+                else:
+                    ndt.comm_destroy()
+            if comm_kind is None:
+                with stdout_to_stderr():                         # RCCL prints its version banner on stdout
+                    ids = [la.NDT.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    ndt.comm_init(rank, world, ids[0])
+                comm_kind = "rccl"
             ranks_seen = ndt.comm_size()
         ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
         pts_rank = float(ndt.source_size())
@@ -520,8 +539,9 @@ def main():
             "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[3]: ONE dense ~2M-point scan sharded over the ranks against the GPU-resident voxel map of a "
-                                   "20M-point map (replicated per rank), RCCL all-reduce of H,b per iteration",
-                       "mode": "sharded", "source_points_per_step_per_gpu": int(pts_rank), "source_points_total": int(pts_all),
+                                   "20M-point map (replicated per rank), all-reduce of H,b per iteration "
+                                   "(p2p: peer stores into the ranks' mailboxes over xGMI; rccl: ncclAllReduce)",
+                       "mode": "sharded", "collective": comm_kind, "source_points_per_step_per_gpu": int(pts_rank), "source_points_total": int(pts_all),
                        "map_points": int(n_map), "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0,
                        "gn_iterations_per_align": a.iters, "parallelism": f"sharded{world}"},
             "scans_per_s": a.steps / el, "poses_identical_across_ranks": identical,

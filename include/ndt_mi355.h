@@ -276,8 +276,25 @@ int ndt_align_batch_resident(ndt_handle* h, const int32_t* pair_scan, size_t n_p
 int ndt_comm_unique_id(char id_out[128]);
 int ndt_comm_init(ndt_handle* h, int rank, int n_ranks, const char id[128]);
 int ndt_comm_destroy(ndt_handle* h);
-/* Ranks of the attached communicator as RCCL counts them (1 when none is attached): what bench.py reports as ranks_seen. */
+/* Ranks of the attached communicator as RCCL counts them, or the ranks of the peer exchange below (1 when neither is
+ * attached): what bench.py reports as ranks_seen. */
 int ndt_comm_size(const ndt_handle* h);
+
+/* The same sharded loop without a collective library, for ranks of ONE node (the case §8(e) sizes: 256 bytes per
+ * iteration, latency-bound): every rank owns a small mailbox in its HBM; on each Gauss-Newton iteration a rank stores its
+ * reduced row straight into every rank's mailbox (xGMI peer stores, system-scope, sequence flags after the rows) and the
+ * next launch sums all ranks' rows in rank order once they have arrived — two launches per iteration instead of three
+ * plus ncclAllReduce, and identical bits on every rank.  ndt_comm_p2p_export allocates the mailbox and returns an opaque
+ * handle (NDT_P2P_HANDLE_BYTES: the HIP IPC handle + the GPU's PCI bus id); the caller distributes the handles of all
+ * ranks, in rank order, as it would RCCL's unique id; ndt_comm_p2p_init opens the peers' mailboxes (at most 16 ranks).
+ * Ranks that share a GPU (rehearsals on a one-GPU box) are detected and wait for the rows in a one-block kernel instead of
+ * in every block's prologue, so that the other rank can run.  Every rank must then make the same sequence of
+ * ndt_align / ndt_eval calls, as with a collective.  A rank that never delivers makes the others return NDT_ERR_COMM
+ * after a bounded wait instead of hanging.  ndt_comm_destroy detaches either kind.  No counterpart in the reference
+ * (`process.cc:377`: its one NDT thread). */
+#define NDT_P2P_HANDLE_BYTES 128
+int ndt_comm_p2p_export(ndt_handle* h, unsigned char handle_out[NDT_P2P_HANDLE_BYTES]);
+int ndt_comm_p2p_init(ndt_handle* h, int rank, int n_ranks, const unsigned char* handles /* n_ranks x NDT_P2P_HANDLE_BYTES */);
 
 /* Several GPUs in ONE process (SURVEY.md §8(b) "multi-GPU: ndt_create_group(n_dev, dev_ids)"; the replay half of
  * §8(e)): a group is one member handle per entry of dev_ids (cfg->device is ignored; a device may be listed more than

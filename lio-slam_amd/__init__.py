@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_align_static", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
-    "ndt_comm_init", "ndt_comm_destroy", "ndt_comm_size", "ndt_time_chain", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_comm_size", "ndt_comm_p2p_export", "ndt_comm_p2p_init", "ndt_time_chain", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version", "ndt_last_radix_passes",
     "ndt_create_group", "ndt_destroy_group", "ndt_group_size", "ndt_group_handle", "ndt_group_set_target", "ndt_group_add_target",
     "ndt_group_align_batch", "ndt_group_last_error",
@@ -138,6 +138,8 @@ def lib():
     L.ndt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ndt_comm_destroy.argtypes = [vp]
     L.ndt_comm_size.argtypes = [vp]
+    L.ndt_comm_p2p_export.argtypes = [vp, vp]
+    L.ndt_comm_p2p_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ndt_time_chain.argtypes = [vp, vp, C.c_int, vp]
     L.ndt_profile.argtypes = [vp, C.c_int]
     L.ndt_profile_read.argtypes = [vp, vp, vp, vp]
@@ -507,6 +509,21 @@ class NDT:
     def comm_init(self, rank, n_ranks, uid):
         buf = C.create_string_buffer(bytes(uid), 128)
         self._chk(lib().ndt_comm_init(self._h, rank, n_ranks, buf))
+
+    # --- the same without a library: peer stores into the ranks' mailboxes (ranks of one node)
+    def comm_p2p_export(self):
+        """Allocates this rank's mailbox; returns its opaque 128-byte handle for the caller to distribute."""
+        buf = C.create_string_buffer(128)
+        self._chk(lib().ndt_comm_p2p_export(self._h, buf))
+        return buf.raw
+
+    def comm_p2p_init(self, rank, n_ranks, handles):
+        """handles: the 128-byte handles of all ranks, in rank order."""
+        blob = b"".join(bytes(x) for x in handles)
+        if len(blob) != 128 * n_ranks:
+            raise ValueError("need one 128-byte handle per rank")
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(lib().ndt_comm_p2p_init(self._h, int(rank), int(n_ranks), buf))
 
     def comm_destroy(self): self._chk(lib().ndt_comm_destroy(self._h))
 

@@ -115,15 +115,25 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 // n_cu: compute units of the handle's device (256 on MI355X; read at ndt_create and kept in the handle): sizes every grid
 int residual_grid(size_t n, int n_cu, size_t problems = 1, int nearby = 7);
 // chained single-scan iteration: previous launch's reduction + step in every block's prologue, then the residual pass
+// Peer exchange of the sharded loop (ndt_comm_p2p_*): every rank owns a mailbox in its own HBM that the other ranks write
+// into over xGMI — [2 parities][NDT_MAX_PEERS ranks][ACC_N] float64 rows, then [2][NDT_MAX_PEERS] 64-bit sequence flags.
+#define NDT_MAX_PEERS 16
+#define PX_ROWS_BYTES (2 * NDT_MAX_PEERS * ACC_N * 8)
+#define PX_BYTES (PX_ROWS_BYTES + 2 * NDT_MAX_PEERS * 8)
+struct PeerWait { const unsigned long long* flags; int n; unsigned long long seq; };   // flags == nullptr: nothing to wait for
+struct PeerRows { double* rows[NDT_MAX_PEERS]; unsigned long long* flags[NDT_MAX_PEERS]; };   // every rank's mailbox at the parity in use
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
-                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, hipStream_t s);
+                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, const PeerWait& pw,
+                           hipStream_t s);
+void launch_reduce_rows_p2p(const double* partials, int n_partials, const GnState* st, const PeerRows& peers, int n_ranks, int rank,
+                            unsigned long long seq, int force, hipStream_t s);
 // (init_state: host pointer or nullptr; given, the launch starts from a fresh state at that pose instead of reading st_in)
 void launch_residual(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, int linked, hipStream_t s);
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve,
-                         int force, GnState* mirror, hipStream_t s);
+                         int force, GnState* mirror, const PeerWait& pw, hipStream_t s);
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s);
 void launch_solve_only(GnState* st, const double* reduced, const SolveParams& sp, int do_solve, int force, hipStream_t s);
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,

@@ -301,6 +301,40 @@ __device__ __forceinline__ void row_group_sums32_on512(const double* __restrict_
 
 struct InitPose { double Rt[12]; int use; };
 
+// Sharded loop, peer exchange: waits (all threads of the block call it) until every rank's row of all-reduce `seq` has
+// arrived in this rank's mailbox — thread r polls rank r's flag — then adds the rows up in rank order into sm[0] (the
+// other RG - 1 groups are zero, so the column tree that follows returns exactly this sum: every loop form and every rank
+// gets the same bits).  Flags and rows are read with system-scope atomic loads, which bypass the caches: no fence here —
+// a system-scope acquire fence in 230 blocks invalidates the L2 under the residual pass that follows (measured: 112 ->
+// 380 us per align).  Bounded: returns false (uniformly) when a peer never delivers; the caller marks the state
+// NDT_ERR_COMM instead of hanging.
+#define PX_SPIN_LIMIT (1 << 21)
+template <int RG>
+__device__ __forceinline__ bool peer_gather(const PeerWait& pw, const double* rows, double (*sm)[ACC_N + 1]) {
+    __shared__ int s_px_ok;
+    if (threadIdx.x == 0) s_px_ok = 1;
+    __syncthreads();
+    if ((int)threadIdx.x < pw.n) {
+        int spins = 0;
+        while (__hip_atomic_load(pw.flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < pw.seq) {
+            if (++spins > PX_SPIN_LIMIT) { s_px_ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();                        // the flags were seen before any row is requested
+    if (threadIdx.x < ACC_N) {
+        const unsigned long long* src = (const unsigned long long*)rows + threadIdx.x;
+        double v = 0.0;
+        for (int r = 0; r < pw.n; ++r)
+            v += __longlong_as_double((long long)__hip_atomic_load(src + (size_t)r * ACC_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        sm[0][threadIdx.x] = v;
+#pragma unroll
+        for (int g = 1; g < RG; ++g) sm[g][threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    return s_px_ok != 0;
+}
+
 // Diagnostic build only (-DNDT_STAMPS, tools/exp_stamps.py): s_memtime at the phase boundaries of the chained launch, from
 // thread 0 of two blocks, into a buffer no other code reads.  The product library is built without it.
 #ifdef NDT_STAMPS
@@ -317,7 +351,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
                                                                 const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
                                                                 const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st_in,
                                                                 GnState* __restrict__ st_out, const double* __restrict__ prev_partials, int n_prev,
-                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init) {
+                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init, PeerWait pw) {
     static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
     __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
@@ -330,12 +364,17 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     // which saves the host-to-device copy in front of the loop (R[9], t[3] are the first twelve words; the rest is zero)
     if (threadIdx.x < ST_WORDS)
         ((double*)&sst)[threadIdx.x] = init.use ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : ((const double*)st_in)[threadIdx.x];
-    if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
+    bool rows_ok = true;                // (sharded loop: the rows are the ranks' rows in this rank's mailbox, once they are all there)
+    if (n_prev > 0 && pw.flags) rows_ok = peer_gather<16>(pw, prev_partials, sm);      // (ends with a barrier too)
+    else if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
     else __syncthreads();
     STAMP(1);
     // (uniform) the rest of the previous step runs in the block's first wave, with no block barrier until the pose is out:
     // column tree, world-frame sums -> H, b (sst still holds the pose the rows were computed at), Gauss-Newton step
-    if (n_prev > 0 && threadIdx.x < 64 && !sst.done) wave0_finish<16>(sm, &sst, sp, true);
+    if (n_prev > 0 && threadIdx.x < 64 && !sst.done) {
+        if (rows_ok) wave0_finish<16>(sm, &sst, sp, true);
+        else if (threadIdx.x == 0) { sst.status = NDT_ERR_COMM; sst.done = 1; }
+    }
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -447,14 +486,15 @@ void launch_residual(const float* x, const float* y, const float* z, int n, cons
 
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
-                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, hipStream_t s) {
+                           const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, const PeerWait& pw,
+                           hipStream_t s) {
     InitPose init{};
     if (init_state) {
         for (int j = 0; j < 9; ++j) init.Rt[j] = init_state->R[j];
         for (int j = 0; j < 3; ++j) init.Rt[9 + j] = init_state->t[j];
         init.use = 1;
     }
-#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init)
+#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init, pw)
     if (ep.nearby == 7) { if (linked) LAUNCH(7, true); else LAUNCH(7, false); }
     else LAUNCH(1, false);
 #undef LAUNCH
@@ -749,15 +789,38 @@ __device__ __forceinline__ void mirror_state(const GnState* st, GnState* mirror)
     for (int i = threadIdx.x & 63; i < (int)(sizeof(GnState) / 8); i += 64) d[i] = s[i];
 }
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
-                                                              SolveParams sp, int do_solve, int force, GnState* mirror) {
+                                                              SolveParams sp, int do_solve, int force, GnState* mirror, PeerWait pw) {
     __shared__ double sm[32][ACC_N + 1];
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
     const int done = st->done;
-    row_group_sums<32>(partials, n_partials, sm, true);
+    bool rows_ok = true;
+    if (pw.flags) rows_ok = peer_gather<32>(pw, partials, sm);      // (sharded loop: the ranks' rows in this rank's mailbox)
+    else row_group_sums<32>(partials, n_partials, sm, true);
     if (threadIdx.x >= 64) return;
-    if (force || !done) wave0_finish<32>(sm, st, sp, do_solve != 0);
+    if (force || !done) {
+        if (rows_ok) wave0_finish<32>(sm, st, sp, do_solve != 0);
+        else if (threadIdx.x == 0) { st->status = NDT_ERR_COMM; st->done = 1; }
+    }
     mirror_state(st, mirror);
+}
+// sharded loop without RCCL: the local fixed-order sum goes straight into every rank's mailbox (this rank's too), row
+// `rank` of the parity in use, with system-scope stores over xGMI; the sequence flags follow the rows (release fence by
+// the one wave that wrote them).  Every rank then sums the same rows in rank order: identical bits everywhere.
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_rows_p2p(const double* __restrict__ partials, int n_partials, const GnState* st, PeerRows peers,
+                                                                 int n_ranks, int rank, unsigned long long seq, int force) {
+    __shared__ double sm[32][ACC_N + 1];
+    row_group_sums<32>(partials, n_partials, sm, force || !st->done);   // a finished state contributes zeros (stale partials)
+    if (threadIdx.x >= 64) return;
+    double v = 0.0;
+    if (threadIdx.x < ACC_N) v = column_tree<32>(sm, threadIdx.x);
+    for (int p = 0; p < n_ranks; ++p)
+        if (threadIdx.x < ACC_N)
+            __hip_atomic_store((unsigned long long*)(peers.rows[p] + (size_t)rank * ACC_N + threadIdx.x), (unsigned long long)__double_as_longlong(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the flags follow the rows: a system-scope release store (this one wave wrote all the rows; waiting for the rows'
+    // acknowledgements alone, without the release, measured the same)
+    if ((int)threadIdx.x < n_ranks) __hip_atomic_store(peers.flags[threadIdx.x] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // multi-GPU form: the local sum goes to a row that RCCL all-reduces, and the step reads the reduced row
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const double* __restrict__ partials, int n_partials, const GnState* st,
@@ -807,8 +870,12 @@ void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnStat
     k_reduce_solve_batch<<<n_pairs, BRED_THREADS, 0, s>>>(partials, rows_per_pair, states, sp, do_solve, force, n_done);
 }
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, GnState* mirror,
-                         hipStream_t s) {
-    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force, mirror);
+                         const PeerWait& pw, hipStream_t s) {
+    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force, mirror, pw);
+}
+void launch_reduce_rows_p2p(const double* partials, int n_partials, const GnState* st, const PeerRows& peers, int n_ranks, int rank,
+                            unsigned long long seq, int force, hipStream_t s) {
+    k_reduce_rows_p2p<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, peers, n_ranks, rank, seq, force);
 }
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s) {
     k_reduce_rows<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, row_out, force);
