@@ -119,13 +119,20 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes
 /* Scan pre-processing on the device, so a LiDAR frame crosses PCIe once:
  * pcl::transformPointCloud(LiDAR->IMU extrinsic) + pcl::VoxelGrid(leaf).filter() of src/slam/src/process.cc:62-73,
  * then setInputSource (process.cc:87).  T may be NULL (no transform).  One centroid (xyz only) per occupied leaf
- * cell, cells in PCL's index order (x fastest, z slowest); non-finite points are skipped as PCL does. */
+ * cell, cells in PCL's index order (x fastest, z slowest); non-finite points are skipped as PCL does.
+ * Differences from the reference, on purpose: pcl::VoxelGrid also averages the other fields of slam_czc::Point
+ * (utility.h:54-61: intensity, time, ring); no later stage of this path reads them, so they are not carried.  And the
+ * reference re-downsamples the WHOLE keyframe map in place after every keyframe (process.cc:137-146) before rebuilding
+ * the NDT target from it; here a keyframe is merged into the voxel statistics instead (ndt_add_target*, below), which
+ * keeps every point's contribution rather than one centroid per 0.5 m cell — the map's voxel means and covariances
+ * therefore differ from a rebuilt-from-downsampled map's by the downsampling error, not by construction. */
 int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes, float leaf,
                                const double T[16]);
 /* Reads the resident source back as packed xyz (xyz may be NULL to ask for the size only). */
 int ndt_get_source(ndt_handle* h, float* xyz, size_t cap_points, size_t* n_out);
 /* The keyframe step of process.cc:134-147 without a host round trip: the resident source, transformed by T, is
- * merged into the resident map (what `*pc_key_ += *output; setInputTarget(pc_key_)` does with pc_trans_filter). */
+ * merged into the resident map (what `*pc_key_ += *output; setInputTarget(pc_key_)` does with pc_trans_filter;
+ * without the in-place re-downsample of process.cc:137-146, see above). */
 int ndt_add_target_from_source(ndt_handle* h, const double T[16]);
 
 /* ndt_.align(*output, guess) + getFinalTransformation() (process.cc:94-95).
