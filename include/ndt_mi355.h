@@ -71,7 +71,12 @@ typedef struct ndt_config {
     double eig_floor_ratio;  /* covariance eigenvalues are raised to ratio*lambda_max (.01)*/
     int32_t final_eval;      /* 1: re-evaluate H,b,chi2 at the returned pose               */
     int32_t device;          /* HIP device ordinal                                          */
+    /* Options of the SLAM-book IncNdt3d the reference's intended form was written against (src/slam/reference/
+     * lio_preinteg.cc:37-38 sets its options).  Both default to 0 = off / PCL's rule. */
+    int32_t max_pts_in_voxel;/* > 0: a voxel that already holds more points than this ignores further merges (IncNdt3d freezes at 50) */
+    int32_t info_rule;       /* NDT_INFO_EIG_CLAMP (PCL: eigenvalue floor) | NDT_INFO_ADD_1E3 (IncNdt3d: (Sigma + 1e-3 I)^-1; one point: 100 I) */
 } ndt_config;
+enum { NDT_INFO_EIG_CLAMP = 0, NDT_INFO_ADD_1E3 = 1 };
 
 /* Output of ndt_align.  Replaces getFinalTransformation() (process.cc:95) and
  * adds what the reference ignores (hasConverged, iteration count) and what the

@@ -101,6 +101,9 @@ class NormalDistributionsTransform {
     // --- parameters PCL leaves at its defaults
     void setNearby(int k) { cfg_.nearby = k; reconfigure(); }
     void setMinPointsPerVoxel(int n) { cfg_.min_pts_in_voxel = n; reconfigure(); }
+    // IncNdt3d's options: freeze voxels beyond n points (0 = never); (Sigma + 1e-3 I)^-1 instead of the eigenvalue floor
+    void setMaxPointsPerVoxel(int n) { cfg_.max_pts_in_voxel = n; reconfigure(); }
+    void setInformationRule(int rule) { cfg_.info_rule = rule; reconfigure(); }
     void setOutlierThreshold(double t) { cfg_.res_outlier_th = t; reconfigure(); }
     const ndt_config& config() const { return cfg_; }
 

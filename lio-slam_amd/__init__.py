@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libndt_mi355.so")
 
 NDT_KEY_FLOOR_F32, NDT_KEY_ROUND_F64 = 0, 1
+NDT_INFO_EIG_CLAMP, NDT_INFO_ADD_1E3 = 0, 1
 ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "NO_TARGET", -3: "NO_SOURCE", -4: "HIP", -5: "TOO_FEW_POINTS",
           -6: "SINGULAR", -7: "KEY_RANGE", -8: "COMM", -9: "CAPACITY"}
 
@@ -44,6 +45,7 @@ class Config(C.Structure):
         ("nearby", C.c_int32), ("min_pts_in_voxel", C.c_int32), ("res_outlier_th", C.c_double),
         ("min_effective_pts", C.c_int32), ("key_rule", C.c_int32), ("eig_floor_ratio", C.c_double),
         ("final_eval", C.c_int32), ("device", C.c_int32),
+        ("max_pts_in_voxel", C.c_int32), ("info_rule", C.c_int32),
     ]
 
 

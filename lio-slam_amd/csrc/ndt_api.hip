@@ -126,6 +126,8 @@ static int check_cfg(const ndt_config* c, std::string& err) {
     if (c->key_rule != NDT_KEY_FLOOR_F32 && c->key_rule != NDT_KEY_ROUND_F64) { err = "unknown key_rule"; return NDT_ERR_INVALID_ARG; }
     if (c->min_pts_in_voxel < 1) { err = "min_pts_in_voxel must be >= 1"; return NDT_ERR_INVALID_ARG; }
     if (!(c->eig_floor_ratio > 0.0) || c->eig_floor_ratio > 1.0) { err = "eig_floor_ratio must be in (0,1]"; return NDT_ERR_INVALID_ARG; }
+    if (c->max_pts_in_voxel < 0) { err = "max_pts_in_voxel must be >= 0"; return NDT_ERR_INVALID_ARG; }
+    if (c->info_rule != NDT_INFO_EIG_CLAMP && c->info_rule != NDT_INFO_ADD_1E3) { err = "unknown info_rule"; return NDT_ERR_INVALID_ARG; }
     return NDT_OK;
 }
 
@@ -170,6 +172,7 @@ void ndt_default_config(ndt_config* c) {
     c->resolution = 1.0f; c->max_iterations = 35; c->eps = 1e-2; c->nearby = 7; c->min_pts_in_voxel = 6;
     c->res_outlier_th = 20.0; c->min_effective_pts = 10; c->key_rule = NDT_KEY_FLOOR_F32; c->eig_floor_ratio = 0.01;
     c->final_eval = 1; c->device = 0;
+    c->max_pts_in_voxel = 0; c->info_rule = NDT_INFO_EIG_CLAMP;
 }
 
 const char* ndt_version(void) { return "ndt_mi355 0.1 (gfx950)"; }
@@ -252,6 +255,7 @@ static int merge_common(ndt_handle* h, const void* pts, size_t n, size_t stride,
         h->build_cfg.kp = key_params(h->cfg);
         h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
         h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+        h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
     }
     double R[9], t[3];
     if (T) {
@@ -345,6 +349,7 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]) {
         h->build_cfg.kp = key_params(h->cfg);
         h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
         h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+        h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
     }
     double R[9], t[3];
     if (T) { for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; } }
@@ -738,6 +743,7 @@ int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes) {
     h->build_cfg.kp = key_params(h->cfg);
     h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
     h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+    h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
     int rc = map_restore(h->map, h->work, h->build_cfg, k.data(), c.data(), m.data(), cv.data(), nv, h->stream, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;

@@ -57,6 +57,8 @@ struct MapBuildCfg {
     KeyParams kp;
     int32_t min_pts;
     double eig_floor_ratio;
+    int32_t max_pts;         // > 0: voxels holding more points than this are frozen (IncNdt3d)
+    int32_t info_rule;       // NDT_INFO_*
 };
 
 // ---- ndt_map.hip

@@ -416,10 +416,31 @@ __device__ inline void jacobi3_dev(const double c[6], double lam[3], double V[3]
 }
 
 // regularised 3x3 inverse + float32 payload (what the residual kernel reads)
-__device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3], const double cv[6], int32_t min_pts, double ratio) {
+__device__ inline void finalize_slot(VoxSlot* sl, int32_t n, const double mu[3], const double cv[6], const MapBuildCfg& cfg) {
+    const int32_t min_pts = cfg.min_pts;
+    const double ratio = cfg.eig_floor_ratio;
     float info[6] = {0, 0, 0, 0, 0, 0};
     int32_t valid = 0;
-    if (n >= min_pts) {
+    if (n >= min_pts && cfg.info_rule == NDT_INFO_ADD_1E3) {
+        // IncNdt3d's rule: info = (Sigma + 1e-3 I)^-1, a single point gets 100 I.  Plain cofactor
+        // inverse in this fixed order (the oracle's finalize_voxel writes the same expressions).
+        if (n == 1) {
+            info[0] = info[3] = info[5] = 100.f;
+            valid = 1;
+        } else {
+            const double a00 = cv[0] + 1e-3, a01 = cv[1], a02 = cv[2], a11 = cv[3] + 1e-3, a12 = cv[4], a22 = cv[5] + 1e-3;
+            const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+            const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+            const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+            const double v[6] = {c00 / det, c01 / det, c02 / det, c11 / det, c12 / det, c22 / det};
+            valid = det > 0.0 && isfinite(det);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if (!isfinite(v[t])) valid = 0;
+                info[t] = (float)v[t];
+            }
+        }
+    } else if (n >= min_pts) {
         double lam[3], V[3][3];
         jacobi3_dev(cv, lam, V);
         double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
@@ -570,7 +591,13 @@ __global__ __launch_bounds__(256) void k_segment_merge(const uint64_t* sk, const
     entry_flag[g] = fresh ? 1u : 0u;    // new table entry        } summed afterwards: a same-address atomic per voxel
     fresh_flag[g] = had == 0 ? 1u : 0u; // new voxel with points  } would serialise
     if (fresh && slot < 4) keys[mask + 1 + slot] = key;      // mirror entries
-    if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
+    if (had != 0 && cfg.max_pts > 0 && had > cfg.max_pts) {      // frozen (IncNdt3d): the voxel keeps what it has
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu[j] = mp[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cv[j] = cp[j];
+        ntot = had;
+    } else if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
         double hm = (double)had, cn = (double)nb, tot = hm + cn;
         double nm[3], dh[3], dc[3];
 #pragma unroll
@@ -605,7 +632,7 @@ __global__ __launch_bounds__(256) void k_finalize_segments(const uint32_t* seg_s
     for (int j = 0; j < 3; ++j) mu[j] = mean[slot * 3 + j];
 #pragma unroll
     for (int j = 0; j < 6; ++j) cv[j] = cov[slot * 6 + j];
-    finalize_slot(&slots[slot], counts[slot], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+    finalize_slot(&slots[slot], counts[slot], mu, cv, cfg);
 }
 
 // pcl::VoxelGrid centroid (src/slam/src/process.cc:68-73): mean of the cell's points, float64 sum in sorted order,
@@ -1202,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict_
 // ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the table,
 // UpdateMeanAndCov with what the voxel held.  Returns the slot; *fresh_entry / *fresh_voxel tell what was new.
 __device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, int64_t key, int64_t* keys, int32_t* counts, double* mean, double* cov,
-                                                uint64_t mask, bool* fresh_entry, bool* fresh_voxel, double mu[3], double cv[6], int32_t* n_total) {
+                                                uint64_t mask, int32_t max_pts, bool* fresh_entry, bool* fresh_voxel, double mu[3], double cv[6], int32_t* n_total) {
     mu[0] = a[0] / nb; mu[1] = a[1] / nb; mu[2] = a[2] / nb;
 #pragma unroll
     for (int j = 0; j < 6; ++j) cv[j] = 0.0;
@@ -1226,7 +1253,13 @@ __device__ __forceinline__ uint32_t merge_voxel(const double a[9], int32_t nb, i
     *fresh_entry = fresh;
     *fresh_voxel = had == 0;
     if (fresh && slot < 4) keys[mask + 1 + slot] = key;      // mirror entries
-    if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
+    if (had != 0 && max_pts > 0 && had > max_pts) {      // frozen (IncNdt3d): the voxel keeps what it has
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mu[j] = mp[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) cv[j] = cp[j];
+        ntot = had;
+    } else if (had != 0) {        // UpdateMeanAndCov (math_utils.h:87-98)
         const double hm = (double)had, cn = (double)nb, tot = hm + cn;
         double nm[3], dh[3], dc[3];
 #pragma unroll
@@ -1277,8 +1310,8 @@ __global__ __launch_bounds__(256) void k_merge_finalize32(const uint4* elems, co
             for (int j = 0; j < 9; ++j) a[j] = sums[(size_t)g * 9 + j];
             bool fe;
             int32_t ntot;
-            const uint32_t slot = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, cap - 1, &fe, &fv, mu, cv, &ntot);
-            finalize_slot(&slots[slot], ntot, mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+            const uint32_t slot = merge_voxel(a, (int32_t)(e - s), key, keys, counts, mean, cov, cap - 1, cfg.max_pts, &fe, &fv, mu, cv, &ntot);
+            finalize_slot(&slots[slot], ntot, mu, cv, cfg);
             slot_of[g] = slot;                                   // for the ghost stage (the sums kernels are done with this array)
             n_new_ent += fe ? 1u : 0u;
         }
@@ -1797,7 +1830,7 @@ __global__ void k_import(const int64_t* in_keys, const int32_t* in_counts, const
     for (int j = 0; j < 3; ++j) { mu[j] = in_mean[(size_t)g * 3 + j]; mean[slot * 3 + j] = mu[j]; }
     for (int j = 0; j < 6; ++j) { cv[j] = in_cov[(size_t)g * 6 + j]; cov[slot * 6 + j] = cv[j]; }
     counts[slot] = in_counts[g];
-    finalize_slot(&slots[slot], in_counts[g], mu, cv, cfg.min_pts, cfg.eig_floor_ratio);
+    finalize_slot(&slots[slot], in_counts[g], mu, cv, cfg);
 }
 
 __global__ void k_export_raw(const int64_t* keys, const int32_t* counts, const double* mean, const double* cov, size_t cap, uint32_t* counter,

@@ -204,6 +204,23 @@ static int finalize_voxel(const ora_handle* h, ora_voxel* v) {
     memset(v->pay_info, 0, sizeof v->pay_info);
     for (int j = 0; j < 3; ++j) v->pay_off[j] = h->quantize ? (double)(float)v->mean_off[j] : v->mean_off[j];
     if (v->n < h->cfg.min_pts_in_voxel) return 0;
+    if (h->cfg.info_rule == NDT_INFO_ADD_1E3) {
+        /* IncNdt3d: info = (Sigma + 1e-3 I)^-1; a single point gets 100 I */
+        double inf[6] = {100.0, 0.0, 0.0, 100.0, 0.0, 100.0};
+        if (v->n > 1) {
+            const double* cv = v->cov;
+            const double a00 = cv[0] + 1e-3, a01 = cv[1], a02 = cv[2], a11 = cv[3] + 1e-3, a12 = cv[4], a22 = cv[5] + 1e-3;
+            const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+            const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+            const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+            if (!(det > 0.0) || !isfinite(det)) return 0;
+            inf[0] = c00 / det; inf[1] = c01 / det; inf[2] = c02 / det; inf[3] = c11 / det; inf[4] = c12 / det; inf[5] = c22 / det;
+        }
+        for (int t = 0; t < 6; ++t) if (!isfinite(inf[t])) return 0;
+        for (int t = 0; t < 6; ++t) v->pay_info[t] = h->quantize ? (double)(float)inf[t] : inf[t];
+        v->valid = 1;
+        return 1;
+    }
     double lam[3], V[3][3];
     jacobi3(v->cov, lam, V);
     double lmax = fmax(lam[0], fmax(lam[1], lam[2]));
@@ -292,6 +309,8 @@ static int merge_points(ora_handle* h, const float* p, size_t n) {
             v->n = nb;
             memcpy(v->mean_off, mu, sizeof mu);
             memcpy(v->cov, cv, sizeof cv);
+        } else if (h->cfg.max_pts_in_voxel > 0 && h->vox[vi].n > h->cfg.max_pts_in_voxel) {
+            /* frozen (IncNdt3d): the voxel keeps what it has */
         } else {
             /* UpdateMeanAndCov (math_utils.h:87-98) */
             ora_voxel* v = &h->vox[vi];

@@ -126,6 +126,37 @@ def test_incremental_merge_parity(mods):
     _cmp_eval(n.eval(c["guess"]), o.eval(c["guess"]))
 
 
+def test_incndt3d_options_parity(mods):
+    """The SLAM-book IncNdt3d options: voxels frozen beyond max_pts_in_voxel points and
+    info = (Sigma + 1e-3 I)^-1 — same map, same evaluation and same aligned pose as the oracle with the same options; and the
+    frozen voxels really stop changing."""
+    la, synth, Oracle = mods
+    c = synth.make_config(1, small=True)
+    rng = np.random.default_rng(6)
+    for opts in (dict(info_rule=1), dict(max_pts_in_voxel=50), dict(max_pts_in_voxel=50, info_rule=1, min_pts_in_voxel=3)):
+        o = Oracle(**opts); n = la.NDT(**opts)
+        o.set_target(c["map"]); n.set_target(c["map"])
+        for k in range(3):
+            T = c["poses"][2 + 3 * k]
+            s = synth.scan(c["scene"], "vlp16", T, rng)
+            before = n.export_voxels()
+            o.add_target(s, T); n.add_target(s, T)
+            after = n.export_voxels()
+            _cmp_maps(after, o.export_voxels())
+            if opts.get("max_pts_in_voxel"):
+                kb = {int(k_): i for i, k_ in enumerate(before["keys"])}
+                frozen = [(kb[int(k_)], j) for j, k_ in enumerate(after["keys"]) if int(k_) in kb and before["counts"][kb[int(k_)]] > 50]
+                assert frozen, "the scene has voxels beyond 50 points"
+                for i, j in frozen:
+                    assert after["counts"][j] == before["counts"][i] and np.array_equal(after["cov"][j], before["cov"][i])
+        o.set_source(c["scan"]); n.set_source(c["scan"])
+        _cmp_eval(n.eval(c["guess"]), o.eval(c["guess"]))
+        rg, ro = n.align(c["guess"]), o.align(c["guess"])
+        assert rg["iterations"] == ro["iterations"]
+        assert np.abs(rg["T"][:3, 3] - ro["T"][:3, 3]).max() < 1e-4
+        n.close()
+
+
 def test_edge_cases(mods):
     la, synth, Oracle = mods
     n = la.NDT()

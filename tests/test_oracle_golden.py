@@ -175,3 +175,30 @@ def test_yard_map_information_matrices(golden):
     o = Oracle()
     o.set_target(m)
     _check_map_against_golden(o.export_voxels(), g)
+
+
+def test_incndt3d_options_of_the_oracle():
+    """max_pts_in_voxel freezes a voxel once it holds more points than that; info_rule ADD_1E3 gives (Sigma + 1e-3 I)^-1
+    (SLAM-book IncNdt3d) — checked against NumPy on a handful of voxels."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(5)
+    cells = np.array([[0, 0, 0], [3, 1, 0], [-2, 4, 1]], np.float32)
+    def cloud(n_per, seed):
+        r = np.random.default_rng(seed)
+        return np.concatenate([c + 0.5 + np.clip(r.normal(0, [0.1, 0.05, 0.01], (n_per, 3)), -0.4, 0.4) for c in cells]).astype(np.float32)
+    a, b = cloud(30, 1), cloud(40, 2)
+    o = Oracle(min_pts_in_voxel=3, info_rule=1, quantize=0)
+    o.set_target(a)
+    vox = o.export_voxels()
+    assert len(vox["keys"]) == 3
+    for i in range(3):
+        assert np.allclose(vox["info"][i], np.linalg.inv(vox["cov"][i] + 1e-3 * np.eye(3)), rtol=1e-9, atol=1e-9)
+    # freeze: 30 points already > max_pts 20, so the merge changes nothing; with max_pts 50 it does
+    o2 = Oracle(min_pts_in_voxel=3, max_pts_in_voxel=20, quantize=0)
+    o2.set_target(a); before = o2.export_voxels(); o2.add_target(b); after = o2.export_voxels()
+    assert np.array_equal(before["counts"], after["counts"]) and np.array_equal(before["mean"], after["mean"]) and np.array_equal(before["cov"], after["cov"])
+    o3 = Oracle(min_pts_in_voxel=3, max_pts_in_voxel=50, quantize=0)
+    o3.set_target(a); o3.add_target(b); merged = o3.export_voxels()
+    assert np.array_equal(merged["counts"], before["counts"] + 40)
+    o3.add_target(b); again = o3.export_voxels()          # 70 > 50: frozen now
+    assert np.array_equal(again["counts"], merged["counts"]) and np.array_equal(again["cov"], merged["cov"])
