@@ -68,8 +68,9 @@ hipError_t map_clear(VoxelMap& m, hipStream_t s);
 struct MapWork {
     DevBuf raw, tx, ty, tz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc, big_pos, big_list, big_sums;
     int32_t* h_plan = nullptr;       // pinned: the 256-byte plan block (misc) as last read back
+    int32_t* h_plan_dev = nullptr;   // the same memory as the device addresses it (kernels leave their results there)
     void release() {
-        if (h_plan) { (void)hipHostFree(h_plan); h_plan = nullptr; }
+        if (h_plan) { (void)hipHostFree(h_plan); h_plan = nullptr; h_plan_dev = nullptr; }
         DevBuf* all[] = {&raw, &tx, &ty, &tz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums};
         for (DevBuf* b : all) b->release();
     }

@@ -105,10 +105,15 @@ __device__ __forceinline__ bool load_target_point(const unsigned char* raw, cons
 }
 
 // WRITE = false: bounding box and valid count only (the fast path reads the input a second time in k_make_elems32)
+// (the keyframe transform travels as a kernel argument: no host-to-device copy in front of the launch; zero_words: the
+// radix passes' tile status words, cleared here by the way — one memset command less before the host's wait)
+struct RtArg { double v[12]; };
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, const double* Rt,
+__global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, RtArg rt,
                                                      KeyParams kp, float* tx, float* ty, float* tz, int64_t* keys, uint32_t* vals,
-                                                     int32_t* block_rows) {
+                                                     int32_t* block_rows, unsigned long long* zero_words, size_t n_zero) {
+    const double* Rt = rt.v;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (size_t)gridDim.x * blockDim.x) zero_words[i] = 0ull;
     __shared__ int32_t smn[3], smx[3], scnt;
     if (threadIdx.x < 3) { smn[threadIdx.x] = INT32_MAX; smx[threadIdx.x] = INT32_MIN; }
     if (threadIdx.x == 0) scnt = 0;
@@ -145,7 +150,13 @@ __global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, c
     if (threadIdx.x < 3) { row[threadIdx.x] = smn[threadIdx.x]; row[3 + threadIdx.x] = smx[threadIdx.x]; }
     if (threadIdx.x == 0) { row[6] = scnt; row[7] = 0; }
 }
-__global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* block_rows, int nrows, int32_t* misc) {
+// Also clears what the rest of the call expects to start at zero — the plan words 40..47, the digit totals and tickets of
+// the radix passes — and leaves the box and the valid count in pinned host memory (`mirror`) as well, so the host needs
+// no memset and no copy command around its one early wait.
+__global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* block_rows, int nrows, int32_t* misc, uint32_t* zero_hist, int n_hist,
+                                                               int32_t* mirror) {
+    for (int i = threadIdx.x; i < n_hist; i += TK_MAX_BLOCKS) zero_hist[i] = 0u;
+    if (threadIdx.x >= 40 && threadIdx.x < 48) misc[threadIdx.x] = 0;
     __shared__ int32_t sm[TK_MAX_BLOCKS / 64][8];
     int32_t v[7] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0};
     if ((int)threadIdx.x < nrows) {
@@ -173,8 +184,9 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
             r = threadIdx.x < 3 ? min(r, x) : threadIdx.x < 6 ? max(r, x) : r + x;
         }
         misc[threadIdx.x] = r;
+        if (mirror) mirror[threadIdx.x] = r;
     }
-    if (threadIdx.x == 7) misc[7] = 0;
+    if (threadIdx.x == 7) { misc[7] = 0; if (mirror) mirror[7] = 0; }
     if (threadIdx.x == 12) misc[12] = 0;
     if (threadIdx.x == 13) misc[13] = 0;
 }
@@ -810,8 +822,9 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act)
 
 // elements + digit totals of every pass (ghist[p][256]); blocks stride over the tiles
 __global__ __launch_bounds__(RS_THREADS) void k_make_elems32(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T,
-                                                             const double* Rt, KeyParams kp, SortKeyMap km, uint32_t invalid_sk, int passes, uint4* elems,
+                                                             RtArg rt, KeyParams kp, SortKeyMap km, uint32_t invalid_sk, int passes, uint4* elems,
                                                              uint32_t* ghist) {
+    const double* Rt = rt.v;
     __shared__ uint32_t h[OS_MAX_PASSES][256];
 #pragma unroll
     for (int p = 0; p < OS_MAX_PASSES; ++p) h[p][threadIdx.x] = 0;
@@ -1041,7 +1054,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_seg_heads32(const uint4* elems, 
 // 64 lanes per segment when voxels hold many points, else 8 (eight segments per wave side by side: at 25 points per voxel
 // the 20 M-point map's 815 k segments took 0.99 ms one wave each, the per-segment chain of dependent loads being the cost)
 __device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 64; }
-__device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? 2048u : 256u; }   // <= 32 trips of a group
+#ifndef SEG_BIG_WIDE
+#define SEG_BIG_WIDE 2048u
+#endif
+__device__ __forceinline__ uint32_t seg_big(uint32_t nseg, uint32_t n_valid) { return seg_wide(nseg, n_valid) ? SEG_BIG_WIDE : 256u; }   // <= 32 trips of a group (8 lanes), <= 8 (64 lanes)
 
 // end of every segment (8 lanes per segment: exponential then 8-ary search on the sorted keys) + the list of big ones
 #define SEG_NONE 0xFFFFFFFFu
@@ -1099,14 +1115,15 @@ __device__ inline void sortkey32_origin(uint32_t sk, const SortKeyMap& km, doubl
 // nine sums of every big segment: one wave per segment up to HUGE_SEG points (waves stride over the front list), one
 // block per longer segment (blocks stride over the back list).  A block per segment for everything above 256 points took
 // 0.37 ms on the 20 M-point map, whose voxels hold 25 points on average and a few hundred near the sensor tracks.
-__global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count, const int32_t* plan,
-                                                            const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg,
-                                                            double* sums) {
+// (block `blk` of `nblk` blocks of BIG_THREADS threads with this role)
+__device__ __forceinline__ void big_sums32_body(uint32_t blk, uint32_t nblk, const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count,
+                                                const int32_t* plan, const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end,
+                                                const SortKeyMap& km, const MapBuildCfg& cfg, double* sums) {
     __shared__ double sm[BIG_THREADS / 64][9];
     const uint32_t n_big = *big_count, n_huge = (uint32_t)plan[PL_HUGECOUNT];
     const int lane = threadIdx.x & 63;
-    const uint32_t n_waves = gridDim.x * (BIG_THREADS / 64);
-    for (uint32_t b = blockIdx.x * (BIG_THREADS / 64) + (threadIdx.x >> 6); b < n_big; b += n_waves) {      // (uniform over the wave)
+    const uint32_t n_waves = nblk * (BIG_THREADS / 64);
+    for (uint32_t b = blk * (BIG_THREADS / 64) + (threadIdx.x >> 6); b < n_big; b += n_waves) {      // (uniform over the wave)
         const uint32_t g = big_list[b];
         const uint32_t s = seg_pos[g], e = seg_end[g];
         int64_t key;
@@ -1138,7 +1155,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_
             for (int j = 0; j < 9; ++j) sums[(size_t)g * 9 + j] = a[j];
         }
     }
-    for (uint32_t b = blockIdx.x; b < n_huge; b += gridDim.x) {       // (uniform over the block)
+    for (uint32_t b = blk; b < n_huge; b += nblk) {       // (uniform over the block)
         const uint32_t g = big_list[list_cap - 1u - b];
         const uint32_t s = seg_pos[g], e = seg_end[g];
         int64_t key;
@@ -1182,13 +1199,16 @@ __global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_
 // One group of L lanes (L = 8 or 64 by the batch's mean points per voxel) per segment, groups striding over the segments:
 // strided sums in voxel-local float64 coordinates over the segment's contiguous elements, xor tree over the group — the
 // same per-lane order and tree as the 64-bit-key kernel above, so both paths give the same bits.  Row g of `sums`.
-__global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos, const uint32_t* seg_end,
-                                                        const int32_t* plan, SortKeyMap km, MapBuildCfg cfg, const uint32_t* big_pos, double* sums) {
+// (block `blk` of `nblk` blocks of BIG_THREADS threads with this role)
+__device__ __forceinline__ void segment_sums32_body(uint32_t blk, uint32_t nblk, const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos,
+                                                    const uint32_t* seg_end, const int32_t* plan, const SortKeyMap& km, const MapBuildCfg& cfg,
+                                                    const uint32_t* big_pos, double* sums) {
     const uint32_t nseg = (uint32_t)plan[PL_NSEG];
     const int L = seg_wide(nseg, n_valid) ? 64 : 8;
     const int lane = threadIdx.x & 63, l = lane & (L - 1), gpw = 64 / L;      // groups per wave
-    const uint32_t groups = gridDim.x * 4u * (uint32_t)gpw;
-    for (uint32_t g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
+    const uint32_t wpb = BIG_THREADS / 64;
+    const uint32_t groups = nblk * wpb * (uint32_t)gpw;
+    for (uint32_t g0 = (blk * wpb + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
         const uint32_t g = g0 + (uint32_t)(lane / L);
         const bool act = g < nseg;
         uint32_t s = 0, e = 0;
@@ -1224,6 +1244,15 @@ __global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict_
             for (int j = 0; j < 9; ++j) sums[(size_t)g * 9 + j] = a[j];
         }
     }
+}
+
+// Both in ONE launch (they do not depend on each other: the big segments' blocks start first and run beside the others;
+// as two launches the second waited for the first's slowest block: 17 + 35 us at 2 M points, 12 + 10 us per keyframe).
+__global__ __launch_bounds__(BIG_THREADS) void k_sums32(uint32_t nb_big, const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count,
+                                                        const int32_t* plan, const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos,
+                                                        const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, const uint32_t* big_pos, double* sums) {
+    if (blockIdx.x < nb_big) big_sums32_body(blockIdx.x, nb_big, big_list, list_cap, big_count, plan, elems, seg_pos, seg_end, km, cfg, sums);
+    else segment_sums32_body(blockIdx.x - nb_big, gridDim.x - nb_big, elems, n_valid, seg_pos, seg_end, plan, km, cfg, big_pos, sums);
 }
 
 // ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the table,
@@ -1388,10 +1417,18 @@ __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 
 #define STAGE_BLOCKS 2048      // grid of the segment-striding kernels
 
+// the pinned 256-byte block the host reads results from, and its device-side address
+static hipError_t ensure_plan_host(MapWork& w) {
+    if (w.h_plan) return hipSuccess;
+    hipError_t e = hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (hipHostGetDevicePointer((void**)&w.h_plan_dev, w.h_plan, 0) != hipSuccess) { (void)hipGetLastError(); w.h_plan_dev = nullptr; }
+    return hipSuccess;
+}
 struct PlanWords { int32_t nseg, sort_err, abort1, abort2, new_vox, new_ent, new_ghost; };
 // the one read-back of a call: the whole 256-byte plan block in one copy into pinned memory
 static int read_plan(MapWork& w, int new_vox_word, int new_ent_word, PlanWords* p, hipStream_t s, std::string& err) {
-    if (!w.h_plan) HIP_TRY(hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault));
+    HIP_TRY(ensure_plan_host(w));
     HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, 256, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int32_t* a = w.h_plan;
@@ -1429,7 +1466,7 @@ static int ghost_stage(VoxelMap& m, MapWork& w, const SegKeys& K, uint32_t items
 
 // Stage 1 of every cloud ingest: staging (host records are copied; device records and SoA arrays are read in place),
 // bounding box of the cells, sort-key layout.  The one read-back every ingest needs: the radix pass count depends on it.
-struct IngestBox { const unsigned char* d_in; double* dRt; size_t n_valid; int32_t misc[8]; SortKeyMap km; int total_bits; uint64_t bbox_cells; };
+struct IngestBox { const unsigned char* d_in; RtArg rt; size_t n_valid; int32_t misc[8]; SortKeyMap km; int total_bits; uint64_t bbox_cells; };
 static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const float* soa_y, const float* soa_z, size_t n, size_t stride, const double* R,
                        const double* t, bool zyx_order, bool write_keys, hipStream_t s, IngestBox* out, std::string& err) {
     const unsigned char* d_in = (const unsigned char*)pts;
@@ -1448,13 +1485,19 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
         }
     }
     HIP_TRY(w.misc.ensure(256));
-    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 160, 0, 32, s));       // the plan words of this call (40..47) start at zero
-    double* dRt = (double*)((char*)w.misc.p + 64);
+    RtArg rt{};
     if (R) {
-        double Rt[12];
-        for (int i = 0; i < 9; ++i) Rt[i] = R[i];
-        for (int i = 0; i < 3; ++i) Rt[9 + i] = t[i];
-        HIP_TRY(hipMemcpyAsync(dRt, Rt, sizeof Rt, hipMemcpyHostToDevice, s));
+        for (int i = 0; i < 9; ++i) rt.v[i] = R[i];
+        for (int i = 0; i < 3; ++i) rt.v[9 + i] = t[i];
+    }
+    HIP_TRY(ensure_plan_host(w));
+    // the fast path's digit totals, tickets and tile status words are cleared by the two kernels below
+    const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const size_t n_status = write_keys ? 0 : (size_t)OS_MAX_PASSES * ntiles * 256;
+    const int n_hist = write_keys ? 0 : (OS_MAX_PASSES + 1) * 256;
+    if (!write_keys) {
+        HIP_TRY(w.hist.ensure((size_t)n_hist * 4));
+        HIP_TRY(w.vals_a.ensure(n_status * 8));
     }
     const unsigned nb256 = (unsigned)((n + 255) / 256);
     const unsigned nb_tk = std::min<unsigned>(nb256, TK_MAX_BLOCKS);
@@ -1462,26 +1505,19 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
     if (write_keys) {
         HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
         HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4));
-        k_target_keys<true><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
-                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+        k_target_keys<true><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, rt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
+                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>(), nullptr, 0);
     } else {
-        k_target_keys<false><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, dRt, kp, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                   w.block_rows.as<int32_t>());
+        k_target_keys<false><<<nb_tk, 256, 0, s>>>(d_in, soa_y, soa_z, n, stride, R ? 1 : 0, rt, kp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                   w.block_rows.as<int32_t>(), w.vals_a.as<unsigned long long>(), n_status);
     }
-    k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>());
+    k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>(), n_hist ? w.hist.as<uint32_t>() : nullptr, n_hist,
+                                              w.h_plan_dev);
     HIP_TRY(hipGetLastError());
-    if (!w.h_plan) HIP_TRY(hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault));
-    if (!write_keys) {       // fast path ahead: its digit totals, tickets and tile status words are zeroed while the host waits
-        const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-        HIP_TRY(w.hist.ensure((size_t)(OS_MAX_PASSES + 1) * 256 * 4));
-        HIP_TRY(w.vals_a.ensure((size_t)OS_MAX_PASSES * ntiles * 256 * 8));
-        HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)(OS_MAX_PASSES + 1) * 256 * 4, s));
-        HIP_TRY(hipMemsetAsync(w.vals_a.p, 0, (size_t)OS_MAX_PASSES * ntiles * 256 * 8, s));
-    }
-    HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
+    if (!w.h_plan_dev) HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(out->misc, w.h_plan, sizeof out->misc);
-    out->d_in = d_in; out->dRt = dRt;
+    out->d_in = d_in; out->rt = rt;
     out->n_valid = (size_t)out->misc[6];
     out->total_bits = 0; out->bbox_cells = 1;
     for (int j = 0; j < 3; ++j) {
@@ -1511,8 +1547,8 @@ int sort_points_by_cell(MapWork& w, const KeyParams& kp, const void* pts, const 
         const unsigned nb_tk = std::min<unsigned>((unsigned)((n + 255) / 256), TK_MAX_BLOCKS);
         HIP_TRY(w.tx.ensure(n * 4)); HIP_TRY(w.ty.ensure(n * 4)); HIP_TRY(w.tz.ensure(n * 4));
         HIP_TRY(w.keys_a.ensure(n * 8)); HIP_TRY(w.vals_a.ensure(n * 4));
-        k_target_keys<true><<<nb_tk, 256, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
-                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>());
+        k_target_keys<true><<<nb_tk, 256, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.rt, kp, w.tx.as<float>(), w.ty.as<float>(), w.tz.as<float>(),
+                                                  w.keys_a.as<int64_t>(), w.vals_a.as<uint32_t>(), w.block_rows.as<int32_t>(), nullptr, 0);
         HIP_TRY(hipGetLastError());
     } else {
         int rc = ingest_bbox(w, kp, pts, soa_y, soa_z, n, stride, R, t, zyx_order, true, s, &box, err);
@@ -1649,7 +1685,7 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     int32_t* plan = w.misc.as<int32_t>();
     const uint32_t invalid_sk = has_invalid ? (uint32_t)(1ull << box.total_bits) : 0xFFFFFFFFu;
     const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));       // >= 8 points per thread
-    k_make_elems32<<<nb_me, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.dRt, cfg.kp, box.km, invalid_sk, P, ea, ghist);
+    k_make_elems32<<<nb_me, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.rt, cfg.kp, box.km, invalid_sk, P, ea, ghist);
     static const bool three_kernel_passes = getenv("NDT_NO_ONESWEEP") != nullptr;        // A/B switch
     auto sort_three_kernels = [&](uint4*& a, uint4*& b) -> int {
         const unsigned nblk = ntiles;
@@ -1694,8 +1730,9 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         if (attempt == 0 || pw.sort_err) {
             k_seg_heads32<<<nb_heads, SH_THREADS, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] starts at zero
             k_seg_ends32<<<nb_seg8, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count);
-            k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, seg_pos, seg_end, box.km, cfg, sums);
-            k_segment_sums32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, seg_end, plan, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
+            const unsigned nb_big = (unsigned)std::min<size_t>(big_ub, 512);
+            k_sums32<<<nb_big + STAGE_BLOCKS / 4, BIG_THREADS, 0, s>>>(nb_big, w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, (uint32_t)n_valid, seg_pos,
+                                                                       seg_end, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
         }
         k_merge_finalize32<<<nb_seg1, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, sums, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)m.cap,
                                                    (uint64_t)m.n_entries, fresh_list, w.big_pos.as<uint32_t>());

@@ -1,0 +1,17 @@
+"""Resident-input map build, timed (2 M-point configs[2] map): min and median of 12 rebuilds."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench, lio_slam_amd as la
+w = bench.load_workload(2, 0, 1, None, False)
+n = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
+d = bench.DeviceCloud(w["map"])
+ts = []
+for _ in range(15):
+    t0 = time.perf_counter(); n.set_target(d.view()); n.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+print("2M build ms: min %.4f median %.4f" % (min(ts[3:]), float(np.median(ts[3:]))), "voxels", n.num_voxels())
+n.set_source(w["scan0"])
+ts = []
+for _ in range(15):
+    t0 = time.perf_counter(); n.add_target_from_source(w["T0"]); n.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+print("118k merge ms: min %.4f median %.4f" % (min(ts[3:]), float(np.median(ts[3:]))))
