@@ -1053,7 +1053,10 @@ __global__ __launch_bounds__(SH_THREADS) void k_seg_heads32(const uint4* elems, 
 // what the segment kernels derive from the segment count, each for itself (no planning kernel in between)
 // 64 lanes per segment when voxels hold many points, else 8 (eight segments per wave side by side: at 25 points per voxel
 // the 20 M-point map's 815 k segments took 0.99 ms one wave each, the per-segment chain of dependent loads being the cost)
-__device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= 64; }
+#ifndef SEG_WIDE_MIN
+#define SEG_WIDE_MIN 256
+#endif
+__device__ __forceinline__ bool seg_wide(uint32_t nseg, uint32_t n_valid) { return nseg && n_valid / nseg >= SEG_WIDE_MIN; }
 #ifndef SEG_BIG_WIDE
 #define SEG_BIG_WIDE 2048u
 #endif
