@@ -200,3 +200,34 @@ def test_dropped_points_never_tie_with_the_max_corner_cell():
     got = n.get_source(); want = voxel_downsample(cloud, 1.0)
     assert got.shape == want.shape == (len(cells), 3) and np.isfinite(got).all()
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_radix_pass_that_gives_up_is_sorted_again(tmp_path):
+    """A one-sweep radix pass whose bounded wait runs out raises a flag; the insert stages then refuse the batch and the host
+    sorts again with the three-kernel passes.  NDT_TEST_SORT_ERR=1 raises the flag after every one-sweep sort (the switch is
+    read once per process, hence the child process): build + merge must give the same map, bit for bit."""
+    import os, subprocess, sys
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import lio_slam_amd as la\n"
+        "from lio_slam_amd import synth\n"
+        "c = synth.make_config(1, small=True)\n"
+        "n = la.NDT(); n.set_target(c['map']); n.add_target(c['scan'], c['guess'])\n"
+        "v = n.export_voxels()\n"
+        "o = np.argsort(v['keys'])\n"
+        "np.savez(sys.argv[1], **{k: np.asarray(x)[o] for k, x in v.items()})\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDT_TEST_SORT_ERR="1")
+    out = tmp_path / "resorted.npz"
+    r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, timeout=150)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    got = np.load(out)
+    c = synth.make_config(1, small=True)
+    n = la.NDT(); n.set_target(c["map"]); n.add_target(c["scan"], c["guess"])
+    v = n.export_voxels()
+    o = np.argsort(v["keys"])
+    for k, x in v.items():
+        assert np.array_equal(np.asarray(x)[o], got[k]), k
