@@ -815,8 +815,11 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act)
     if (act && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(m));
 }
 
-#define OS_ITEMS 16
-#define OS_TILE (RS_THREADS * OS_ITEMS)        // 4096 elements per tile
+#define OS_ITEMS 16                  // elements per thread of a tile: 4096 per tile; small batches use OS_ITEMS_SMALL (1024 per tile)
+#define OS_ITEMS_SMALL 4
+#define OS_SMALL_N (1u << 19)         // below this many elements a keyframe-sized batch: more, shorter tiles
+#define OS_TILE (RS_THREADS * OS_ITEMS)
+static inline int os_items_for(size_t n) { return n < OS_SMALL_N ? OS_ITEMS_SMALL : OS_ITEMS; }
 #define OS_MAX_PASSES 4
 #define GH_COPIES 8                 // copies of the digit totals the blocks add into (by block index): 977 same-address adds in a row cost 15 us
 #define GH_STRIDE (OS_MAX_PASSES * 256)
@@ -877,6 +880,7 @@ extern "C" int ndt_debug_os_stamps(unsigned long long* out, int tiles) { return 
 #else
 #define OS_STAMP(k) do { } while (0)
 #endif
+template <int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
                                                            const uint32_t* __restrict__ ghist, unsigned long long* status, uint32_t* ticket, int32_t* err) {
     __shared__ uint32_t s_tile;
@@ -895,17 +899,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
     OS_STAMP(1);
     // element order inside a tile: (wave, round, lane) — every wave owns 1024 consecutive elements, so ranking needs no
     // block barrier per round
-    const size_t base = (size_t)tile * OS_TILE + (size_t)w * (64 * OS_ITEMS) + lane;
-    uint4 e[OS_ITEMS];
+    const size_t base = (size_t)tile * (RS_THREADS * ITEMS) + (size_t)w * (64 * ITEMS) + lane;
+    uint4 e[ITEMS];
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const size_t i = base + (size_t)r * 64;
         e[r] = i < n ? in[i] : make_uint4(0, 0, 0, 0);
     }
-    uint32_t rank[OS_ITEMS];               // rank of the element among the wave's elements of the same digit, in element order
+    uint32_t rank[ITEMS];               // rank of the element among the wave's elements of the same digit, in element order
     volatile uint32_t* wc = wcnt[w];
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const bool act = base + (size_t)r * 64 < n;
         const unsigned d = (e[r].x >> shift) & 255u;
         const unsigned long long am = __ballot(act);
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep32(const uint4* __restri
     wcnt[0][threadIdx.x] = p0; wcnt[1][threadIdx.x] = p0 + c0; wcnt[2][threadIdx.x] = p0 + c0 + c1; wcnt[3][threadIdx.x] = p0 + c0 + c1 + c2;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         if (base + (size_t)r * 64 < n) {
             const uint32_t pos = wcnt[w][(e[r].x >> shift) & 255u] + rank[r];
             if (pos < n) out[pos] = e[r];        // (always, unless a wait ran out)
@@ -1503,7 +1507,8 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
     }
     HIP_TRY(ensure_plan_host(w));
     // the fast path's digit totals, tickets and tile status words are cleared by the two kernels below
-    const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const size_t tile_elems = (size_t)RS_THREADS * os_items_for(n);
+    const size_t ntiles = (n + tile_elems - 1) / tile_elems;
     const size_t n_status = write_keys ? 0 : (size_t)OS_MAX_PASSES * ntiles * 256;
     const int n_hist = write_keys ? 0 : (GH_COPIES * OS_MAX_PASSES + 1) * 256;
     if (!write_keys) {
@@ -1685,7 +1690,8 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     const size_t n_valid = box.n_valid;
     const int P = std::max(1, (box.total_bits + (has_invalid ? 1 : 0) + 7) / 8);      // <= 4
     if (passes) *passes = P;
-    const unsigned ntiles = (unsigned)((n + OS_TILE - 1) / OS_TILE);
+    const int os_items = os_items_for(n);
+    const unsigned ntiles = (unsigned)((n + (size_t)RS_THREADS * os_items - 1) / ((size_t)RS_THREADS * os_items));
     const size_t status_words = (size_t)ntiles * 256;
     HIP_TRY(w.keys_a.ensure(n * 16)); HIP_TRY(w.keys_b.ensure(n * 16));
     // hist: [P][256] digit totals, [P] tickets (padded to 256 words); vals_a: the tiles' status words of every pass
@@ -1695,11 +1701,11 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
     uint32_t* tickets = ghist + GH_COPIES * GH_STRIDE;
     int32_t* plan = w.misc.as<int32_t>();
     const uint32_t invalid_sk = has_invalid ? (uint32_t)(1ull << box.total_bits) : 0xFFFFFFFFu;
-    const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));       // >= 8 points per thread
+    const unsigned nb_me = (unsigned)std::min<size_t>(ME_MAX_BLOCKS, (n + RS_THREADS * 4 - 1) / (RS_THREADS * 4));       // one trip of four points per thread while that fits
     k_make_elems32<<<nb_me, RS_THREADS, 0, s>>>(box.d_in, soa_y, soa_z, n, stride, R ? 1 : 0, box.rt, cfg.kp, box.km, invalid_sk, P, ea, ghist);
     static const bool three_kernel_passes = getenv("NDT_NO_ONESWEEP") != nullptr;        // A/B switch
     auto sort_three_kernels = [&](uint4*& a, uint4*& b) -> int {
-        const unsigned nblk = ntiles;
+        const unsigned nblk = (unsigned)((n + OS_TILE - 1) / OS_TILE);
         const size_t nh = (size_t)256 * nblk;
         HIP_TRY(w.vals_b.ensure(nh * 4));
         HIP_TRY(w.scan_tmp.ensure(((nh + SCAN_TILE - 1) / SCAN_TILE + 2) * 4));
@@ -1718,15 +1724,17 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         // tiles that are all resident at once take their block index as their number (no ticket queue)
         if (!w.os_resident) {
             int per_cu = 0, dev = 0, n_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onesweep32, RS_THREADS, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onesweep32<OS_ITEMS>, RS_THREADS, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
                 hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && n_cu > 0)
                 w.os_resident = (unsigned)(per_cu * n_cu);
             else { (void)hipGetLastError(); w.os_resident = 1; }
         }
         const bool numbered_by_block = ntiles <= w.os_resident;
         for (int p = 0; p < P; ++p) {
-            k_onesweep32<<<ntiles, RS_THREADS, 0, s>>>(ea, eb, (uint32_t)n, 8 * p, ghist + p * 256, w.vals_a.as<unsigned long long>() + (size_t)p * status_words,
-                                                       numbered_by_block ? nullptr : tickets + p, plan + PL_SORT_ERR);
+            unsigned long long* st_p = w.vals_a.as<unsigned long long>() + (size_t)p * status_words;
+            uint32_t* tk = numbered_by_block ? nullptr : tickets + p;
+            if (os_items == OS_ITEMS) k_onesweep32<OS_ITEMS><<<ntiles, RS_THREADS, 0, s>>>(ea, eb, (uint32_t)n, 8 * p, ghist + p * 256, st_p, tk, plan + PL_SORT_ERR);
+            else k_onesweep32<OS_ITEMS_SMALL><<<ntiles, RS_THREADS, 0, s>>>(ea, eb, (uint32_t)n, 8 * p, ghist + p * 256, st_p, tk, plan + PL_SORT_ERR);
             std::swap(ea, eb);
         }
         static const bool test_sort_err = getenv("NDT_TEST_SORT_ERR") != nullptr;      // tests: pretend a pass gave up
