@@ -386,7 +386,9 @@ def main():
         def frame(f, timed):
             nonlocal merges, pts_done
             j = (f + rank) % 8
-            rc = L.ndt_set_source(h, dev[j].ptr, dev[j].n, 12)
+            # the frame is in HBM already and stays there: stream-ordered hand-over (the unpack runs on the engine's stream in front
+            # of the align's kernels, inside the timed region; there is no host wait in between)
+            rc = L.ndt_set_source_async(h, dev[j].ptr, dev[j].n, 12)
             rc = rc or L.ndt_align(h, g16[j].ctypes.data, ctypes.byref(res))
             if rc:
                 raise la.NdtError(rc, L.ndt_last_error(h).decode())

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "ndt_default_config", "ndt_create", "ndt_destroy", "ndt_configure", "ndt_set_target", "ndt_add_target",
     "ndt_set_source", "ndt_set_source_downsampled", "ndt_get_source", "ndt_add_target_from_source", "ndt_align", "ndt_align_static", "ndt_eval", "ndt_source_cells", "ndt_source_size", "ndt_num_voxels",
     "ndt_export_voxels", "ndt_map_save", "ndt_map_load", "ndt_pcl_default_params", "ndt_pcl_eval", "ndt_pcl_align", "ndt_pcl_time_pass", "ndt_pcl_vector_from_matrix", "ndt_pcl_matrix_from_vector", "ndt_information_from_hessian", "ndt_pack_key", "ndt_unpack_key", "ndt_align_batch", "ndt_set_batch_sources", "ndt_align_batch_resident", "ndt_comm_unique_id",
-    "ndt_comm_init", "ndt_comm_destroy", "ndt_comm_size", "ndt_comm_p2p_export", "ndt_comm_p2p_init", "ndt_time_chain", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
+    "ndt_comm_init", "ndt_comm_destroy", "ndt_comm_size", "ndt_comm_p2p_export", "ndt_comm_p2p_init", "ndt_set_source_async", "ndt_time_chain", "ndt_profile", "ndt_profile_read", "ndt_time_residual", "ndt_time_residual_batch", "ndt_synchronize",
     "ndt_last_error", "ndt_version", "ndt_last_radix_passes",
     "ndt_create_group", "ndt_destroy_group", "ndt_group_size", "ndt_group_handle", "ndt_group_set_target", "ndt_group_add_target",
     "ndt_group_align_batch", "ndt_group_last_error",
@@ -96,6 +96,7 @@ def lib():
     L.ndt_set_target.argtypes = [vp, vp, sz, sz]
     L.ndt_add_target.argtypes = [vp, vp, sz, sz, vp]
     L.ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.ndt_set_source_async.argtypes = [vp, vp, sz, sz]
     L.ndt_set_source_downsampled.argtypes = [vp, vp, sz, sz, C.c_float, vp]
     L.ndt_get_source.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.ndt_add_target_from_source.argtypes = [vp, vp]
@@ -322,6 +323,12 @@ class NDT:
     def set_source(self, pts):
         keep, p, n, s = _points(pts)
         self._chk(lib().ndt_set_source(self._h, p, n, s))
+
+    def set_source_async(self, dev_view):
+        """dev_view = (device pointer, n, stride): records in this device's memory, read on the engine's stream; they must stay
+        valid until a later call that returns results has returned."""
+        keep, p, n, s = _points(dev_view)
+        self._chk(lib().ndt_set_source_async(self._h, p, n, s))
 
     def set_source_downsampled(self, pts, leaf=0.5, T=None):
         """process.cc:62-73 + 87 on the device: extrinsic transform, VoxelGrid(leaf) centroids, set as the source."""

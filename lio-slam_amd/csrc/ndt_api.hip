@@ -272,7 +272,7 @@ int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride, cons
     return merge_common(h, pts, n, stride, T, false);
 }
 
-int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
+static int set_source_impl(ndt_handle* h, const void* pts, size_t n, size_t stride, bool stream_ordered) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 source points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
@@ -282,7 +282,9 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
         // records already in this device's memory are unpacked in place (the unpack kernel is their only reader and has
         // finished when this call returns); host records are staged through sraw
         const void* d_in = pts;
-        if (!points_on_device(pts, h->cfg.device)) {
+        const bool on_device = points_on_device(pts, h->cfg.device);
+        if (stream_ordered && !on_device) { h->err = "ndt_set_source_async takes records in this device's memory"; return NDT_ERR_INVALID_ARG; }
+        if (!on_device) {
             H_TRY(h->sraw.ensure(n * stride + 16));
             H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
             d_in = h->sraw.p;
@@ -291,11 +293,13 @@ int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) {
     }
     H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
     H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
-    H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
+    if (!stream_ordered) H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
     h->n_src = n;
     h->have_source = true;
     return NDT_OK;
 }
+int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride) { return set_source_impl(h, pts, n, stride, false); }
+int ndt_set_source_async(ndt_handle* h, const void* d_pts, size_t n, size_t stride) { return set_source_impl(h, d_pts, n, stride, true); }
 
 // ---- scan pre-processing on the device
 

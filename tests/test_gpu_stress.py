@@ -231,3 +231,32 @@ def test_radix_pass_that_gives_up_is_sorted_again(tmp_path):
     o = np.argsort(v["keys"])
     for k, x in v.items():
         assert np.array_equal(np.asarray(x)[o], got[k]), k
+
+
+def test_stream_ordered_source_gives_the_same_align():
+    """ndt_set_source_async (device records, no host wait) followed by align = ndt_set_source + align, bit for bit; a host
+    pointer is refused."""
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    import bench
+    c = synth.make_config(1, small=True)
+    n = la.NDT()
+    n.set_target(c["map"])
+    n.set_source(c["scan"])
+    r0 = n.align(c["guess"])
+    d = bench.DeviceCloud(c["scan"])
+    try:
+        other = bench.DeviceCloud(c["scan"][: len(c["scan"]) // 2])
+        try:
+            n.set_source_async(other.view()); n.align(c["guess"], check=False)
+            n.set_source_async(d.view())
+            r1 = n.align(c["guess"])
+            assert n.source_size() == len(c["scan"])
+        finally:
+            other.free()
+    finally:
+        d.free()
+    assert np.array_equal(r0["T"], r1["T"]) and np.array_equal(r0["H"], r1["H"]) and r0["iterations"] == r1["iterations"]
+    with pytest.raises(la.NdtError) as ei:
+        n.set_source_async(c["scan"])
+    assert ei.value.rc == -1
