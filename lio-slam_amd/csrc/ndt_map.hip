@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void segment_sums32_body(uint32_t blk, uint32_t nblk,
     const uint32_t nseg = (uint32_t)plan[PL_NSEG];
     const int L = seg_wide(nseg, n_valid) ? 64 : 8;
     const int lane = threadIdx.x & 63, l = lane & (L - 1), gpw = 64 / L;      // groups per wave
-    const uint32_t wpb = BIG_THREADS / 64;
+    const uint32_t wpb = blockDim.x >> 6;
     const uint32_t groups = nblk * wpb * (uint32_t)gpw;
     for (uint32_t g0 = (blk * wpb + (threadIdx.x >> 6)) * (uint32_t)gpw; g0 < nseg; g0 += groups) {
         const uint32_t g = g0 + (uint32_t)(lane / L);
@@ -1260,13 +1260,28 @@ __device__ __forceinline__ void segment_sums32_body(uint32_t blk, uint32_t nblk,
     }
 }
 
+// large batches: a launch each (256-thread blocks suit the per-segment sums better once the launch gap no longer matters:
+// 20 M points 164 us as two launches, 193 us as one)
+__global__ __launch_bounds__(BIG_THREADS) void k_big_sums32(const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count, const int32_t* plan,
+                                                            const uint4* elems, const uint32_t* seg_pos, const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg,
+                                                            double* sums) {
+    big_sums32_body(blockIdx.x, gridDim.x, big_list, list_cap, big_count, plan, elems, seg_pos, seg_end, km, cfg, sums);
+}
+__global__ __launch_bounds__(256) void k_segment_sums32(const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos, const uint32_t* seg_end,
+                                                        const int32_t* plan, SortKeyMap km, MapBuildCfg cfg, const uint32_t* big_pos, double* sums) {
+    segment_sums32_body(blockIdx.x, gridDim.x, elems, n_valid, seg_pos, seg_end, plan, km, cfg, big_pos, sums);
+}
 // Both in ONE launch (they do not depend on each other: the big segments' blocks start first and run beside the others;
 // as two launches the second waited for the first's slowest block: 17 + 35 us at 2 M points, 12 + 10 us per keyframe).
 __global__ __launch_bounds__(BIG_THREADS) void k_sums32(uint32_t nb_big, const uint32_t* big_list, uint32_t list_cap, const uint32_t* big_count,
                                                         const int32_t* plan, const uint4* __restrict__ elems, uint32_t n_valid, const uint32_t* seg_pos,
                                                         const uint32_t* seg_end, SortKeyMap km, MapBuildCfg cfg, const uint32_t* big_pos, double* sums) {
-    if (blockIdx.x < nb_big) big_sums32_body(blockIdx.x, nb_big, big_list, list_cap, big_count, plan, elems, seg_pos, seg_end, km, cfg, sums);
-    else segment_sums32_body(blockIdx.x - nb_big, gridDim.x - nb_big, elems, n_valid, seg_pos, seg_end, plan, km, cfg, big_pos, sums);
+    // the two roles alternate over the block index while both last, so that neither waits for the other's blocks to drain
+    const uint32_t nb_seg = gridDim.x - nb_big, m = nb_big < nb_seg ? nb_big : nb_seg, b = blockIdx.x;
+    const bool big_role = b < 2 * m ? (b & 1u) == 0u : nb_big > nb_seg;
+    const uint32_t idx = b < 2 * m ? b >> 1 : b - m;
+    if (big_role) big_sums32_body(idx, nb_big, big_list, list_cap, big_count, plan, elems, seg_pos, seg_end, km, cfg, sums);
+    else segment_sums32_body(idx, nb_seg, elems, n_valid, seg_pos, seg_end, plan, km, cfg, big_pos, sums);
 }
 
 // ComputeMeanAndCov of the batch's points of one voxel from their nine sums, find-or-insert in the table,
@@ -1761,9 +1776,15 @@ int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void
         if (attempt == 0 || pw.sort_err) {
             k_seg_heads32<<<nb_heads, SH_THREADS, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan);       // plan[PL_NSEG] starts at zero
             k_seg_ends32<<<nb_seg8, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, plan, seg_end, w.big_pos.as<uint32_t>(), w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count);
-            const unsigned nb_big = (unsigned)std::min<size_t>(big_ub, 512);
-            k_sums32<<<nb_big + STAGE_BLOCKS / 4, BIG_THREADS, 0, s>>>(nb_big, w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, (uint32_t)n_valid, seg_pos,
-                                                                       seg_end, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
+            if (n_valid < (4u << 20)) {
+                const unsigned nb_big = (unsigned)std::min<size_t>(big_ub, 512);
+                k_sums32<<<nb_big + STAGE_BLOCKS / 4, BIG_THREADS, 0, s>>>(nb_big, w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, (uint32_t)n_valid,
+                                                                           seg_pos, seg_end, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
+            } else {
+                k_big_sums32<<<(unsigned)std::min<size_t>(big_ub, 1024), BIG_THREADS, 0, s>>>(w.big_list.as<uint32_t>(), (uint32_t)big_ub, big_count, plan, ea, seg_pos,
+                                                                                              seg_end, box.km, cfg, sums);
+                k_segment_sums32<<<STAGE_BLOCKS, 256, 0, s>>>(ea, (uint32_t)n_valid, seg_pos, seg_end, plan, box.km, cfg, w.big_pos.as<uint32_t>(), sums);
+            }
         }
         k_merge_finalize32<<<nb_seg1, 256, 0, s>>>(ea, seg_pos, seg_end, plan, box.km, cfg, sums, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)m.cap,
                                                    (uint64_t)m.n_entries, fresh_list, w.big_pos.as<uint32_t>());

@@ -15,3 +15,11 @@ ts = []
 for _ in range(15):
     t0 = time.perf_counter(); n.add_target_from_source(w["T0"]); n.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
 print("118k merge ms: min %.4f median %.4f" % (min(ts[3:]), float(np.median(ts[3:]))))
+if len(sys.argv) > 1 and sys.argv[1] == "large":
+    lm = bench.large_map_workload()
+    n2 = la.NDT(max_iterations=10, eps=0.0, final_eval=0)
+    d2 = bench.DeviceCloud(lm["map"])
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter(); n2.set_target(d2.view()); n2.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+    print("20M build ms: min %.4f median %.4f" % (min(ts[2:]), float(np.median(ts[2:]))), "voxels", n2.num_voxels())
