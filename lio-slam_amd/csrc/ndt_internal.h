@@ -34,7 +34,6 @@ struct VoxelMap {          // the GPU-resident voxel hash
     size_t cap = 0;            // power of two (0 = no map)
     int64_t n_vox = 0;         // voxels that hold points
     int64_t n_entries = 0;     // occupied slots: voxels + ghost cells (what the load factor counts)
-    int32_t* d_n_vox = nullptr;
 };
 
 struct SortKeyMap {        // packed key <-> compact radix-sort key for one batch; entry 0 is the most significant axis

@@ -42,8 +42,6 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     if ((e = hipMalloc((void**)&m.counts, cap * sizeof(int32_t))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.mean, cap * 3 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&m.cov, cap * 6 * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&m.d_n_vox, 256)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(m.d_n_vox, 0, 256, s)) != hipSuccess) return e;
     m.cap = cap;
     m.n_vox = 0; m.n_entries = 0;
     k_init_slots<<<init_slots_grid(cap), 256, 0, s>>>(m.slots, m.keys, m.counts, cap);
@@ -52,8 +50,6 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
 // empties the table in place (keeps the allocation: a rebuild of a same-sized map allocates nothing)
 hipError_t map_clear(VoxelMap& m, hipStream_t s) {
     if (!m.cap) return hipSuccess;
-    hipError_t e = hipMemsetAsync(m.d_n_vox, 0, 256, s);
-    if (e != hipSuccess) return e;
     m.n_vox = 0; m.n_entries = 0;
     k_init_slots<<<init_slots_grid(m.cap), 256, 0, s>>>(m.slots, m.keys, m.counts, m.cap);
     return hipGetLastError();
@@ -64,7 +60,6 @@ void map_free(VoxelMap& m) {
     if (m.counts) (void)hipFree(m.counts);
     if (m.mean) (void)hipFree(m.mean);
     if (m.cov) (void)hipFree(m.cov);
-    if (m.d_n_vox) (void)hipFree(m.d_n_vox);
     m = VoxelMap();
 }
 
