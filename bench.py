@@ -378,6 +378,11 @@ def main():
         Tk16 = [np.ascontiguousarray(w[f"T{j}"].T).reshape(16) for j in range(8)]
         L = la.lib(); h = ndt._h
         res = la.Result()
+        # (argument objects made once: building a ctypes pointer per call costs a microsecond each, 2 % of a frame)
+        res_ref = ctypes.byref(res)
+        g_ptr = [ctypes.c_void_p(x.ctypes.data) for x in g16]
+        Tk_ptr = [ctypes.c_void_p(x.ctypes.data) for x in Tk16]
+        d_ptr = [(d.ptr, ctypes.c_size_t(d.n), ctypes.c_size_t(12)) for d in dev]
         n_frames = a.warmup + a.steps
         n_gate = 0 if a.no_cpu or rank != 0 else min(a.steps, max(12, a.keyframe_every + 2))
         gate_T = []
@@ -388,8 +393,8 @@ def main():
             j = (f + rank) % 8
             # the frame is in HBM already and stays there: stream-ordered hand-over (the unpack runs on the engine's stream in front
             # of the align's kernels, inside the timed region; there is no host wait in between)
-            rc = L.ndt_set_source_async(h, dev[j].ptr, dev[j].n, 12)
-            rc = rc or L.ndt_align(h, g16[j].ctypes.data, ctypes.byref(res))
+            rc = L.ndt_set_source_async(h, *d_ptr[j])
+            rc = rc or L.ndt_align(h, g_ptr[j], res_ref)
             if rc:
                 raise la.NdtError(rc, L.ndt_last_error(h).decode())
             if timed:
@@ -400,7 +405,7 @@ def main():
                     gate_T.append(np.array(res.T).reshape(4, 4).T.copy())
             if f % a.keyframe_every == a.keyframe_every - 1:                   # keyframe: the resident source joins the map
                 t1 = time.perf_counter()
-                rc = L.ndt_add_target_from_source(h, Tk16[j].ctypes.data)
+                rc = L.ndt_add_target_from_source(h, Tk_ptr[j])
                 if rc:
                     raise la.NdtError(rc, L.ndt_last_error(h).decode())
                 if timed:
