@@ -71,6 +71,7 @@ struct ndt_handle {
     unsigned char* static_scratch = nullptr;   // this device's copy of g_static_scratch (ndt_align_static), resolved at ndt_create
     bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
+    unsigned long long mirror_seq = 0;      // count of results requested through the mirror (the kernel echoes it after the state)
     GnState* h_state_dev = nullptr;   // the same memory as the device addresses it (the last kernel of a chained loop writes the result there)
     std::string err;
     int last_radix_passes = 0;
@@ -202,7 +203,7 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
         hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&h->d_state, sizeof(GnState)) != hipSuccess ||
         hipMalloc((void**)&h->d_state2, sizeof(GnState)) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_state, sizeof(GnState) + 64, hipHostMallocDefault) != hipSuccess ||
         static_scratch_for_device(cfg->device, &h->static_scratch) != hipSuccess) {
         ndt_destroy(h);
         return nullptr;
@@ -443,7 +444,7 @@ static int queue_pass(ndt_handle* h, const SourceView& src, int grid, double* ro
         // order (the same kernel as the single-GPU step, with the wait for the rows in front)
         const unsigned long long seq = ++h->px.seq;
         launch_reduce_rows_p2p(rows, grid, st, px_rows(h, seq), h->px.n, h->px.rank, seq, force, h->stream);
-        launch_reduce_solve(px_local_rows(h, seq), h->px.n, st, sp, do_solve, force, nullptr, px_wait(h, seq), h->stream);
+        launch_reduce_solve(px_local_rows(h, seq), h->px.n, st, sp, do_solve, force, nullptr, 0, px_wait(h, seq), h->stream);
     } else if (h->comm) {
         // local fixed-order sum into the send row, all-reduce into the receive row, then the same step on
         // every rank.  A finished state still takes part in the collective (its rows are ignored), so the
@@ -455,7 +456,7 @@ static int queue_pass(ndt_handle* h, const SourceView& src, int grid, double* ro
         if (rc != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
         launch_solve_only(st, recv, sp, do_solve, force, h->stream);
     } else {
-        launch_reduce_solve(rows, grid, st, sp, do_solve, force, nullptr, PeerWait{nullptr, 0, 0}, h->stream);
+        launch_reduce_solve(rows, grid, st, sp, do_solve, force, nullptr, 0, PeerWait{nullptr, 0, 0}, h->stream);
     }
     H_TRY(hipGetLastError());
     return NDT_OK;
@@ -524,6 +525,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
     const bool chained_comm = chain_fits && h->comm && h->px.n == 0;
     // (a prologue that waits occupies every CU while it waits: only when no other rank needs this GPU to produce its row)
     const bool chained_p2p = chain_fits && h->px.n > 0 && !h->px.shared_device;
+    unsigned long long mirror_want = 0;
     int cur = 0;                        // B.st[cur] is the current state; the chained launches ping-pong
     int rcur = 0;                       // B.rows[rcur] is where the next launch writes its rows
     // the chained loop's first launch takes the initial pose as a kernel argument; the other forms read it from HBM
@@ -546,7 +548,8 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
                 cur ^= 1;               // the launch published the state it used in the other buffer
                 rcur ^= 1;              // rows[rcur ^ 1] = the rows just written
             }
-            launch_reduce_solve(B.rows[rcur ^ 1], grid, B.st[cur], sp, 1, 0, h->h_state_dev, PeerWait{nullptr, 0, 0}, h->stream);
+            mirror_want = ++h->mirror_seq;
+            launch_reduce_solve(B.rows[rcur ^ 1], grid, B.st[cur], sp, 1, 0, h->h_state_dev, mirror_want, PeerWait{nullptr, 0, 0}, h->stream);
             H_TRY(hipGetLastError());
         } else if (chained_comm) {
             // sharded source: launch i takes the step from the all-reduced row of launch i - 1 in its prologue (one "row" to sum),
@@ -574,7 +577,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
                 seq = ++h->px.seq;
                 launch_reduce_rows_p2p(B.rows[0], grid, B.st[cur], px_rows(h, seq), h->px.n, h->px.rank, seq, 0, h->stream);
             }
-            launch_reduce_solve(px_local_rows(h, seq), h->px.n, B.st[cur], sp, 1, 0, nullptr, px_wait(h, seq), h->stream);
+            launch_reduce_solve(px_local_rows(h, seq), h->px.n, B.st[cur], sp, 1, 0, nullptr, 0, px_wait(h, seq), h->stream);
             H_TRY(hipGetLastError());
         } else {
             for (int i = 0; i < m; ++i)
@@ -582,8 +585,22 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
         }
         queued += m;
         // (the chained loop's last kernel has written the state into the pinned buffer itself: one command fewer to wait for)
-        if (!(chained && h->h_state_dev)) H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
-        H_TRY(hipStreamSynchronize(h->stream));
+        if (chained && h->h_state_dev) {
+            // poll the word the kernel writes after the state (bounded by the stream's own completion)
+            volatile unsigned long long* flag = (volatile unsigned long long*)((unsigned char*)h->h_state + sizeof(GnState));
+            static const bool poll = getenv("NDT_NO_POLL") == nullptr;
+            bool seen = false;
+            for (unsigned k = 1; poll && !seen; ++k) {
+                seen = *flag == mirror_want;
+                if (!seen && (k & 255u) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+                __builtin_ia32_pause();
+            }
+            if (!seen) H_TRY(hipStreamSynchronize(h->stream));
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        } else {
+            H_TRY(hipMemcpyAsync(h->h_state, B.st[cur], sizeof(GnState), hipMemcpyDeviceToHost, h->stream));
+            H_TRY(hipStreamSynchronize(h->stream));
+        }
         if (h->h_state->done) break;
     }
     const GnState loop = *h->h_state;

@@ -136,7 +136,7 @@ void launch_residual(const float* x, const float* y, const float* z, int n, cons
                      const GnState* st, const EvalParams& ep, double* partials, int grid, int force,
                      int64_t* keys_out, uint8_t* mask_out, int linked, hipStream_t s);
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve,
-                         int force, GnState* mirror, const PeerWait& pw, hipStream_t s);
+                         int force, GnState* mirror, unsigned long long mirror_seq, const PeerWait& pw, hipStream_t s);
 void launch_reduce_rows(const double* partials, int n_partials, const GnState* st, double* row_out, int force, hipStream_t s);
 void launch_solve_only(GnState* st, const double* reduced, const SolveParams& sp, int do_solve, int force, hipStream_t s);
 void launch_residual_batch(const float* x, const float* y, const float* z, const int64_t* scan_off, const int32_t* pair_scan,

@@ -781,15 +781,19 @@ __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* s
 // The first wave leaves a copy of the state in `mirror` (pinned host memory the device can write; nullptr: no copy), so
 // the host reads the result after its stream wait without a copy command in between.
 static_assert(sizeof(GnState) % 8 == 0, "mirror_state copies 8-byte words");
-__device__ __forceinline__ void mirror_state(const GnState* st, GnState* mirror) {
+// The word after the state gets `seq` once the copy is out (system-scope release): a host that polls it sees the result a
+// few microseconds before the stream's completion signal would tell it.
+__device__ __forceinline__ void mirror_state(const GnState* st, GnState* mirror, unsigned long long seq) {
     if (!mirror) return;
     __threadfence();                          // the lanes' stores to *st are done before other lanes read them back
     const unsigned long long* s = (const unsigned long long*)st;
     unsigned long long* d = (unsigned long long*)mirror;
     for (int i = threadIdx.x & 63; i < (int)(sizeof(GnState) / 8); i += 64) d[i] = s[i];
+    __threadfence_system();                   // (every lane: its words are out before lane 0's flag)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(d + sizeof(GnState) / 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __restrict__ partials, int n_partials, GnState* st,
-                                                              SolveParams sp, int do_solve, int force, GnState* mirror, PeerWait pw) {
+                                                              SolveParams sp, int do_solve, int force, GnState* mirror, unsigned long long mirror_seq, PeerWait pw) {
     __shared__ double sm[32][ACC_N + 1];
     // the rows are summed unconditionally (their loads overlap the read of st->done); a finished state just
     // discards the result
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve(const double* __re
         if (rows_ok) wave0_finish<32>(sm, st, sp, do_solve != 0);
         else if (threadIdx.x == 0) { st->status = NDT_ERR_COMM; st->done = 1; }
     }
-    mirror_state(st, mirror);
+    mirror_state(st, mirror, mirror_seq);
 }
 // sharded loop without RCCL: the local fixed-order sum goes straight into every rank's mailbox (this rank's too), row
 // `rank` of the parity in use, with system-scope stores over xGMI; the sequence flags follow the rows (release fence by
@@ -870,8 +874,8 @@ void launch_reduce_solve_batch(const double* partials, int rows_per_pair, GnStat
     k_reduce_solve_batch<<<n_pairs, BRED_THREADS, 0, s>>>(partials, rows_per_pair, states, sp, do_solve, force, n_done);
 }
 void launch_reduce_solve(const double* partials, int n_partials, GnState* st, const SolveParams& sp, int do_solve, int force, GnState* mirror,
-                         const PeerWait& pw, hipStream_t s) {
-    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force, mirror, pw);
+                         unsigned long long mirror_seq, const PeerWait& pw, hipStream_t s) {
+    k_reduce_solve<<<1, RED_THREADS, 0, s>>>(partials, n_partials, st, sp, do_solve, force, mirror, mirror_seq, pw);
 }
 void launch_reduce_rows_p2p(const double* partials, int n_partials, const GnState* st, const PeerRows& peers, int n_ranks, int rank,
                             unsigned long long seq, int force, hipStream_t s) {
