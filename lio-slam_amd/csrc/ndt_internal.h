@@ -68,6 +68,7 @@ struct MapWork {
     DevBuf raw, tx, ty, tz, block_rows, keys_a, keys_b, vals_a, vals_b, hist, flags, flags2, segid, seg_start, scan_tmp, misc, big_pos, big_list, big_sums;
     int32_t* h_plan = nullptr;       // pinned: the 256-byte plan block (misc) as last read back
     int32_t* h_plan_dev = nullptr;   // the same memory as the device addresses it (kernels leave their results there)
+    int32_t plan_seq = 0;            // sequence number of the last result requested through the pinned block
     unsigned os_resident = 0;        // tiles of the one-sweep radix pass the device holds at once (0: not asked yet)
     void release() {
         if (h_plan) { (void)hipHostFree(h_plan); h_plan = nullptr; h_plan_dev = nullptr; }

@@ -83,6 +83,7 @@ hipError_t unpack_points_soa(const void* d_raw, size_t n, size_t stride, float* 
 // Same-address global atomics from thousands of blocks serialise (~11 ns each), so every block writes one row
 // of partials and a single block folds the rows.
 #define TK_MAX_BLOCKS 1024
+#define PLAN_SEQ_WORD 63          // word of the pinned 256-byte block that carries the sequence number the host polls
 // Input is AoS records (raw, stride) or, when stride == 0, three SoA arrays (raw = x, soa_y, soa_z).
 // one input point: AoS record or SoA arrays, optional keyframe transform (pcl::transformPointCloud, process.cc:134-136:
 // float64 math, one rounding to float32), PCL's cell rule.  Returns false for a dropped point (non-finite / out of key range).
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_target_keys(const unsigned char* raw, c
 // the radix passes — and leaves the box and the valid count in pinned host memory (`mirror`) as well, so the host needs
 // no memset and no copy command around its one early wait.
 __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* block_rows, int nrows, int32_t* misc, uint32_t* zero_hist, int n_hist,
-                                                               int32_t* mirror) {
+                                                               int32_t* mirror, int32_t mirror_seq) {
     for (int i = threadIdx.x; i < n_hist; i += TK_MAX_BLOCKS) zero_hist[i] = 0u;
     if (threadIdx.x >= 40 && threadIdx.x < 48) misc[threadIdx.x] = 0;
     __shared__ int32_t sm[TK_MAX_BLOCKS / 64][8];
@@ -182,6 +183,10 @@ __global__ __launch_bounds__(TK_MAX_BLOCKS) void k_bbox_reduce(const int32_t* bl
         if (mirror) mirror[threadIdx.x] = r;
     }
     if (threadIdx.x == 7) { misc[7] = 0; if (mirror) mirror[7] = 0; }
+    if (mirror && threadIdx.x < 64) {          // (the first wave wrote all the mirrored words) the word the host polls
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(mirror + PLAN_SEQ_WORD, mirror_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (threadIdx.x == 12) misc[12] = 0;
     if (threadIdx.x == 13) misc[13] = 0;
 }
@@ -1442,6 +1447,26 @@ __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 
 #define STAGE_BLOCKS 2048      // grid of the segment-striding kernels
 
+// The host's waits of a build / merge: kernels leave what the host needs in the pinned block and write a sequence word
+// after it (system-scope release); the host polls that word instead of waiting for the stream's completion signal, which
+// arrives a few microseconds later (the poll is bounded by the stream's own state).
+__global__ __launch_bounds__(64) void k_publish_plan(const int32_t* misc, int32_t* mirror, int32_t seq) {
+    if (threadIdx.x < PLAN_SEQ_WORD) mirror[threadIdx.x] = misc[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(mirror + PLAN_SEQ_WORD, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static hipError_t wait_plan(MapWork& w, hipStream_t s) {
+    static const bool poll = getenv("NDT_NO_POLL") == nullptr;
+    if (w.h_plan_dev && poll) {
+        volatile int32_t* flag = w.h_plan + PLAN_SEQ_WORD;
+        for (unsigned k = 1;; ++k) {
+            if (*flag == w.plan_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
+            if ((k & 255u) == 0 && hipStreamQuery(s) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+    }
+    return hipStreamSynchronize(s);
+}
 // the pinned 256-byte block the host reads results from, and its device-side address
 static hipError_t ensure_plan_host(MapWork& w) {
     if (w.h_plan) return hipSuccess;
@@ -1454,8 +1479,9 @@ struct PlanWords { int32_t nseg, sort_err, abort1, abort2, new_vox, new_ent, new
 // the one read-back of a call: the whole 256-byte plan block in one copy into pinned memory
 static int read_plan(MapWork& w, int new_vox_word, int new_ent_word, PlanWords* p, hipStream_t s, std::string& err) {
     HIP_TRY(ensure_plan_host(w));
-    HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, 256, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (w.h_plan_dev) k_publish_plan<<<1, 64, 0, s>>>(w.misc.as<int32_t>(), w.h_plan_dev, ++w.plan_seq);
+    else HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, 256, hipMemcpyDeviceToHost, s));
+    HIP_TRY(wait_plan(w, s));
     const int32_t* a = w.h_plan;
     *p = PlanWords{a[PL_NSEG], a[PL_SORT_ERR], a[PL_ABORT1], a[PL_ABORT2], a[new_vox_word], a[new_ent_word], a[PL_NEW_GHOST]};
     return NDT_OK;
@@ -1538,10 +1564,10 @@ static int ingest_bbox(MapWork& w, const KeyParams& kp, const void* pts, const f
                                                    w.block_rows.as<int32_t>(), w.vals_a.as<unsigned long long>(), n_status);
     }
     k_bbox_reduce<<<1, TK_MAX_BLOCKS, 0, s>>>(w.block_rows.as<int32_t>(), (int)nb_tk, w.misc.as<int32_t>(), n_hist ? w.hist.as<uint32_t>() : nullptr, n_hist,
-                                              w.h_plan_dev);
+                                              w.h_plan_dev, ++w.plan_seq);
     HIP_TRY(hipGetLastError());
     if (!w.h_plan_dev) HIP_TRY(hipMemcpyAsync(w.h_plan, w.misc.p, sizeof out->misc, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(wait_plan(w, s));
     memcpy(out->misc, w.h_plan, sizeof out->misc);
     out->d_in = d_in; out->rt = rt;
     out->n_valid = (size_t)out->misc[6];
