@@ -15,6 +15,11 @@ d = bench.DeviceCloud(w["map"])
 for _ in range(3):
     ndt.set_target(d.view()); ndt.synchronize()
 nt = (len(w["map"]) + 4095) // 4096
+if len(sys.argv) > 1 and sys.argv[1] == "merge":       # a keyframe merge instead: 1024-element tiles
+    ndt.set_source(w["scan0"])
+    for _ in range(3):
+        ndt.add_target_from_source(w["T0"]); ndt.synchronize()
+    nt = (len(w["scan0"]) + 1023) // 1024
 buf = (ctypes.c_ulonglong * (8 * nt))()
 assert la.lib().ndt_debug_os_stamps(buf, nt) == 0
 st = np.array(list(buf), dtype=np.int64).reshape(nt, 8)[:, :6]
