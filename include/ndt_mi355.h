@@ -121,9 +121,10 @@ int ndt_add_target(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes
 /* ndt_.setInputSource(pc_trans_filter) (process.cc:87).  The records are copied: the caller's buffer is free on return. */
 int ndt_set_source(ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
 /* The same for records that already lie in this device's memory (a LiDAR driver or a pre-processing kernel left them
- * there), stream-ordered: the records are unpacked on the handle's stream and the call returns without waiting.  d_pts
- * must stay valid and unchanged until a later call on this handle that returns results has returned (ndt_align,
- * ndt_eval, ndt_add_target_from_source, ndt_synchronize, ...).  A host pointer is refused (NDT_ERR_INVALID_ARG). */
+ * there), stream-ordered: the call returns at once; the records are read on the handle's stream by the first kernel that
+ * needs the source (the first launch of ndt_align's loop unpacks them by the way; any other reader runs an unpack kernel
+ * first).  d_pts must stay valid and unchanged until a later call on this handle that reads the source has returned
+ * (ndt_align, ndt_eval, ndt_add_target_from_source, ndt_get_source, ...).  A host pointer is refused (NDT_ERR_INVALID_ARG). */
 int ndt_set_source_async(ndt_handle* h, const void* d_pts, size_t n, size_t stride_bytes);
 
 /* Scan pre-processing on the device, so a LiDAR frame crosses PCIe once:

@@ -71,6 +71,7 @@ struct ndt_handle {
     unsigned char* static_scratch = nullptr;   // this device's copy of g_static_scratch (ndt_align_static), resolved at ndt_create
     bool use_chain = true;                     // NDT_NO_CHAIN=1: two launches per iteration (A/B switch)
     GnState* h_state = nullptr;  // pinned
+    const unsigned char* src_aos = nullptr; size_t src_aos_stride = 0;   // ndt_set_source_async: records not yet unpacked into sx / sy / sz
     unsigned long long mirror_seq = 0;      // count of results requested through the mirror (the kernel echoes it after the state)
     GnState* h_state_dev = nullptr;   // the same memory as the device addresses it (the last kernel of a chained loop writes the result there)
     std::string err;
@@ -104,6 +105,7 @@ struct ndt_handle {
 };
 
 #define H_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { h->err = std::string(#x) + ": " + hipGetErrorString(e_); return NDT_ERR_HIP; } } while (0)
+static int ensure_source_soa(ndt_handle* h);
 
 // true when p is device memory of device `dev` (a plain host pointer makes the query fail: that is not an error)
 static bool points_on_device(const void* p, int dev) {
@@ -164,7 +166,7 @@ static hipError_t static_scratch_for_device(int dev, unsigned char** out) {
 // where one Gauss-Newton loop keeps its device-side working state: rows[2] are partial-row buffers (>= grid rows each),
 // st[2] the two states the chained loop ping-pongs between
 struct GnBuffers { double* rows[2]; GnState* st[2]; };
-struct SourceView { const float *x, *y, *z; size_t n; };
+struct SourceView { const float *x, *y, *z; size_t n; AosIn aos; };
 
 extern "C" {
 
@@ -290,8 +292,10 @@ static int set_source_impl(ndt_handle* h, const void* pts, size_t n, size_t stri
             H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
             d_in = h->sraw.p;
         }
-        H_TRY(unpack_points_soa(d_in, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
-    }
+        h->src_aos = nullptr;
+        if (stream_ordered) { h->src_aos = (const unsigned char*)d_in; h->src_aos_stride = stride; }      // unpacked by the first launch that reads the source
+        else H_TRY(unpack_points_soa(d_in, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
+    } else h->src_aos = nullptr;
     H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
     H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
     if (!stream_ordered) H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
@@ -336,6 +340,7 @@ int ndt_get_source(ndt_handle* h, float* xyz, size_t cap, size_t* n_out) {
     if (cap < h->n_src) { h->err = "output buffer smaller than the source"; return NDT_ERR_CAPACITY; }
     if (!h->n_src) return NDT_OK;
     H_TRY(hipSetDevice(h->cfg.device));
+    { int rc = ensure_source_soa(h); if (rc != NDT_OK) return rc; }
     std::vector<float> tmp(h->n_src * 3);
     H_TRY(hipMemcpyAsync(tmp.data(), h->sx.p, h->n_src * 4, hipMemcpyDeviceToHost, h->stream));
     H_TRY(hipMemcpyAsync(tmp.data() + h->n_src, h->sy.p, h->n_src * 4, hipMemcpyDeviceToHost, h->stream));
@@ -349,6 +354,7 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
     H_TRY(hipSetDevice(h->cfg.device));
+    { int rc = ensure_source_soa(h); if (rc != NDT_OK) return rc; }
     if (!h->have_target) {
         H_TRY(map_clear(h->map, h->stream));
         h->build_cfg.kp = key_params(h->cfg);
@@ -383,11 +389,12 @@ static void unpack_acc(const double* acc, double H[36], double b[6]) {
         for (int c = r; c < 6; ++c, ++t) { if (H) { H[r * 6 + c] = acc[t]; H[c * 6 + r] = acc[t]; } }
     if (b) for (int r = 0; r < 6; ++r) b[r] = acc[21 + r];
 }
-static int ready(ndt_handle* h) {
+static int ensure_source_soa(ndt_handle* h);
+static int ready(ndt_handle* h, bool keep_pending_records = false) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
     if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
-    return NDT_OK;
+    return keep_pending_records ? NDT_OK : ensure_source_soa(h);
 }
 static EvalParams eval_params(const ndt_handle* h) {
     EvalParams ep;
@@ -410,7 +417,18 @@ static hipEvent_t next_event(ndt_handle* h) {
     }
     return h->ev_pool[h->ev_used++];
 }
-static SourceView resident_source(const ndt_handle* h) { return SourceView{h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->n_src}; }
+static SourceView resident_source(const ndt_handle* h) {
+    SourceView v{h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->n_src, AosIn{nullptr, 0, nullptr, nullptr, nullptr}};
+    if (h->src_aos) v.aos = AosIn{h->src_aos, (uint32_t)h->src_aos_stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>()};
+    return v;
+}
+// everything but the chained loop's first launch reads the three arrays: unpack records that are still pending
+static int ensure_source_soa(ndt_handle* h) {
+    if (!h->src_aos) return NDT_OK;
+    H_TRY(unpack_points_soa(h->src_aos, h->n_src, h->src_aos_stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
+    h->src_aos = nullptr;
+    return NDT_OK;
+}
 static GnBuffers handle_buffers(const ndt_handle* h) { return GnBuffers{{h->partials.as<double>(), h->partials2.as<double>()}, {h->d_state, h->d_state2}}; }
 // peer exchange: the mailboxes at the parity all-reduce `seq` uses
 static PeerRows px_rows(const ndt_handle* h, unsigned long long seq) {
@@ -526,6 +544,8 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
     // (a prologue that waits occupies every CU while it waits: only when no other rank needs this GPU to produce its row)
     const bool chained_p2p = chain_fits && h->px.n > 0 && !h->px.shared_device;
     unsigned long long mirror_want = 0;
+    AosIn aos = src.aos;                // records still to be unpacked: the chained loop's first launch does it by the way
+    if (aos.p && !chained) { int rc0 = ensure_source_soa(h); if (rc0 != NDT_OK) return rc0; aos.p = nullptr; }
     int cur = 0;                        // B.st[cur] is the current state; the chained launches ping-pong
     int rcur = 0;                       // B.rows[rcur] is where the next launch writes its rows
     // the chained loop's first launch takes the initial pose as a kernel argument; the other forms read it from HBM
@@ -543,7 +563,8 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
             for (int i = 0; i < m; ++i) {
                 launch_residual_chain(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), B.st[cur], B.st[cur ^ 1],
                                       B.rows[rcur ^ 1], i ? grid : 0, sp, ep, B.rows[rcur], grid, h->use_links, first_launch ? &init_state : nullptr,
-                                      PeerWait{nullptr, 0, 0}, h->stream);
+                                      PeerWait{nullptr, 0, 0}, aos, h->stream);
+                if (aos.p) { aos.p = nullptr; h->src_aos = nullptr; }      // the arrays are current from here on (stream order)
                 first_launch = false;
                 cur ^= 1;               // the launch published the state it used in the other buffer
                 rcur ^= 1;              // rows[rcur ^ 1] = the rows just written
@@ -558,7 +579,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
             double* recv = send + ACC_N;
             for (int i = 0; i < m; ++i) {
                 launch_residual_chain(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), B.st[cur], B.st[cur ^ 1], recv,
-                                      i ? 1 : 0, sp, ep, B.rows[0], grid, h->use_links, nullptr, PeerWait{nullptr, 0, 0}, h->stream);
+                                      i ? 1 : 0, sp, ep, B.rows[0], grid, h->use_links, nullptr, PeerWait{nullptr, 0, 0}, AosIn{nullptr, 0, nullptr, nullptr, nullptr}, h->stream);
                 cur ^= 1;
                 launch_reduce_rows(B.rows[0], grid, B.st[cur], send, 0, h->stream);
                 if (g_rccl.all_reduce(send, recv, ACC_N, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream) != 0) { h->err = "ncclAllReduce failed"; return NDT_ERR_COMM; }
@@ -572,7 +593,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
             for (int i = 0; i < m; ++i) {
                 launch_residual_chain(src.x, src.y, src.z, (int)src.n, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1), B.st[cur], B.st[cur ^ 1],
                                       i ? px_local_rows(h, seq) : nullptr, i ? h->px.n : 0, sp, ep, B.rows[0], grid, h->use_links, nullptr,
-                                      i ? px_wait(h, seq) : PeerWait{nullptr, 0, 0}, h->stream);
+                                      i ? px_wait(h, seq) : PeerWait{nullptr, 0, 0}, AosIn{nullptr, 0, nullptr, nullptr, nullptr}, h->stream);
                 cur ^= 1;
                 seq = ++h->px.seq;
                 launch_reduce_rows_p2p(B.rows[0], grid, B.st[cur], px_rows(h, seq), h->px.n, h->px.rank, seq, 0, h->stream);
@@ -629,7 +650,7 @@ static int gn_loop(ndt_handle* h, const SourceView& src, int grid, const GnBuffe
 }
 
 int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out) {
-    int rc = ready(h);
+    int rc = ready(h, true);
     if (rc != NDT_OK) return rc;
     if (!guess || !out) { h->err = "null argument"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
@@ -664,7 +685,7 @@ int ndt_align_static(ndt_handle* h, const float* d_x, const float* d_y, const fl
     // every call on this GPU shares the array and finds the last call's contents in it: the two states start at zero
     // (the rows need no clearing: a launch writes each of its rows in full before any kernel reads them)
     H_TRY(hipMemsetAsync(base + 2 * STATIC_ROWS_BYTES, 0, 2 * STATIC_STATE_BYTES, h->stream));
-    return gn_loop(h, SourceView{d_x, d_y, d_z, n}, grid, B, guess, out);
+    return gn_loop(h, SourceView{d_x, d_y, d_z, n, AosIn{nullptr, 0, nullptr, nullptr, nullptr}}, grid, B, guess, out);
 }
 
 int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mean, double* cov, double* info, uint8_t* valid,
@@ -1174,7 +1195,7 @@ int ndt_time_chain(ndt_handle* h, const double T[16], int reps, double* us_per_l
     auto pass = [&]() {
         launch_residual_chain(h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), (int)h->n_src, h->map.keys, h->map.slots, (uint32_t)(h->map.cap - 1),
                               B.st[cur], B.st[cur ^ 1], B.rows[rcur ^ 1], first ? 0 : grid, sp, ep, B.rows[rcur], grid, h->use_links, first ? &init : nullptr,
-                              PeerWait{nullptr, 0, 0}, h->stream);
+                              PeerWait{nullptr, 0, 0}, AosIn{nullptr, 0, nullptr, nullptr, nullptr}, h->stream);
         first = false; cur ^= 1; rcur ^= 1;
     };
     for (int i = 0; i < 3; ++i) pass();   // warm

@@ -124,12 +124,15 @@ int residual_grid(size_t n, int n_cu, size_t problems = 1, int nearby = 7);
 #define NDT_MAX_PEERS 16
 #define PX_ROWS_BYTES (2 * NDT_MAX_PEERS * ACC_N * 8)
 #define PX_BYTES (PX_ROWS_BYTES + 2 * NDT_MAX_PEERS * 8)
+// Records still to be unpacked (ndt_set_source_async): the first launch that reads the source takes them from here and
+// leaves the three-array copy behind for everything after it.  p == nullptr: the arrays are current.
+struct AosIn { const unsigned char* p; uint32_t stride; float *ox, *oy, *oz; };
 struct PeerWait { const unsigned long long* flags; int n; unsigned long long seq; };   // flags == nullptr: nothing to wait for
 struct PeerRows { double* rows[NDT_MAX_PEERS]; unsigned long long* flags[NDT_MAX_PEERS]; };   // every rank's mailbox at the parity in use
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
                            const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, const PeerWait& pw,
-                           hipStream_t s);
+                           const AosIn& aos, hipStream_t s);
 void launch_reduce_rows_p2p(const double* partials, int n_partials, const GnState* st, const PeerRows& peers, int n_ranks, int rank,
                             unsigned long long seq, int force, hipStream_t s);
 // (init_state: host pointer or nullptr; given, the launch starts from a fresh state at that pose instead of reading st_in)

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
                                                                 const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
                                                                 const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st_in,
                                                                 GnState* __restrict__ st_out, const double* __restrict__ prev_partials, int n_prev,
-                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init, PeerWait pw) {
+                                                                SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init, PeerWait pw, AosIn aos) {
     static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
     __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
@@ -359,7 +359,15 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     STAMP(0);
     int i = blockIdx.x * RES1_THREADS + threadIdx.x;
     float xf = 0.f, yf = 0.f, zf = 0.f;
-    if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    // (aos.p: the first launch after ndt_set_source_async reads the caller's records and leaves the three-array copy for the
+    // launches after it — every point is read by exactly one lane of one block — instead of an unpack kernel in front)
+    if (i < n) {
+        if (aos.p) {
+            const float* r = (const float*)(aos.p + (size_t)i * aos.stride);
+            xf = r[0]; yf = r[1]; zf = r[2];
+            aos.ox[i] = xf; aos.oy[i] = yf; aos.oz[i] = zf;
+        } else { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+    }
     // the state: from st_in, or (first launch of an align) a fresh one at the pose that came as a kernel argument,
     // which saves the host-to-device copy in front of the loop (R[9], t[3] are the first twelve words; the rest is zero)
     if (threadIdx.x < ST_WORDS)
@@ -395,7 +403,13 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
         if (LINKED) point_terms_linked(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         else point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         i += gridDim.x * RES1_THREADS;
-        if (i < n) { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+        if (i < n) {
+            if (aos.p) {
+                const float* r = (const float*)(aos.p + (size_t)i * aos.stride);
+                xf = r[0]; yf = r[1]; zf = r[2];
+                aos.ox[i] = xf; aos.oy[i] = yf; aos.oz[i] = zf;
+            } else { xf = xs[i]; yf = ys[i]; zf = zs[i]; }
+        }
     }
     STAMP(4);
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
@@ -487,14 +501,14 @@ void launch_residual(const float* x, const float* y, const float* z, int n, cons
 void launch_residual_chain(const float* x, const float* y, const float* z, int n, const int64_t* keys, const VoxSlot* slots, uint32_t mask,
                            const GnState* st_in, GnState* st_out, const double* prev_partials, int n_prev, const SolveParams& sp,
                            const EvalParams& ep, double* partials, int grid, int linked, const GnState* init_state, const PeerWait& pw,
-                           hipStream_t s) {
+                           const AosIn& aos, hipStream_t s) {
     InitPose init{};
     if (init_state) {
         for (int j = 0; j < 9; ++j) init.Rt[j] = init_state->R[j];
         for (int j = 0; j < 3; ++j) init.Rt[9 + j] = init_state->t[j];
         init.use = 1;
     }
-#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init, pw)
+#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init, pw, aos)
     if (ep.nearby == 7) { if (linked) LAUNCH(7, true); else LAUNCH(7, false); }
     else LAUNCH(1, false);
 #undef LAUNCH

@@ -260,3 +260,25 @@ def test_stream_ordered_source_gives_the_same_align():
     with pytest.raises(la.NdtError) as ei:
         n.set_source_async(c["scan"])
     assert ei.value.rc == -1
+    # the records stay pending until something reads the source: every reader must find them (eval, read-back, keyframe
+    # merge, and the two-launch loop), not only the chained loop's first launch
+    e0 = n.eval(c["guess"])
+    d = bench.DeviceCloud(c["scan"])
+    try:
+        n.set_source_async(d.view()); e1 = n.eval(c["guess"])
+        assert np.array_equal(e0["H"], e1["H"]) and e0["n_effective"] == e1["n_effective"]
+        n.set_source_async(d.view())
+        assert np.array_equal(n.get_source(), c["scan"][:, :3])
+        m0 = la.NDT(); m0.set_target(c["map"]); m0.set_source(c["scan"]); m0.add_target_from_source(c["guess"])
+        m1 = la.NDT(); m1.set_target(c["map"]); m1.set_source_async(d.view()); m1.add_target_from_source(c["guess"])
+        v0, v1 = m0.export_voxels(), m1.export_voxels()
+        o0, o1 = np.argsort(v0["keys"]), np.argsort(v1["keys"])
+        for k in v0:
+            assert np.array_equal(np.asarray(v0[k])[o0], np.asarray(v1[k])[o1]), k
+        m1.set_source_async(d.view()); m1.profile(True)            # profiling uses the two-launch loop
+        rp = m1.align(c["guess"]); m1.profile(False)
+        m0.set_source(c["scan"]); rq = m0.align(c["guess"])
+        assert np.array_equal(rp["T"], rq["T"])
+        m0.close(); m1.close()
+    finally:
+        d.free()
