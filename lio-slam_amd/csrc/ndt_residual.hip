@@ -525,61 +525,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
-// sin and cos of a rotation step: Taylor series to x^19 / x^18 up to 0.8 rad (truncation < 1e-20), the library
-// routine beyond (a Gauss-Newton step of more than 45 degrees: rare)
-__device__ __forceinline__ void step_sincos(double x, double* s, double* c) {
-    if (fabs(x) > 0.8) { sincos(x, s, c); return; }
-    const double x2 = x * x;
-    double ps = -1.0 / 121645100408832000.0;            // 1/19!
-    ps = fma(ps, x2, 1.0 / 355687428096000.0);           // 1/17!
-    ps = fma(ps, x2, -1.0 / 1307674368000.0);            // 1/15!
-    ps = fma(ps, x2, 1.0 / 6227020800.0);                // 1/13!
-    ps = fma(ps, x2, -1.0 / 39916800.0);                 // 1/11!
-    ps = fma(ps, x2, 1.0 / 362880.0);                    // 1/9!
-    ps = fma(ps, x2, -1.0 / 5040.0);                     // 1/7!
-    ps = fma(ps, x2, 1.0 / 120.0);                       // 1/5!
-    ps = fma(ps, x2, -1.0 / 6.0);                        // 1/3!
-    *s = fma(ps * x2, x, x);
-    double pc = 1.0 / 6402373705728000.0;                // 1/18!
-    pc = fma(pc, x2, -1.0 / 20922789888000.0);           // 1/16!
-    pc = fma(pc, x2, 1.0 / 87178291200.0);               // 1/14!
-    pc = fma(pc, x2, -1.0 / 479001600.0);                // 1/12!
-    pc = fma(pc, x2, 1.0 / 3628800.0);                   // 1/10!
-    pc = fma(pc, x2, -1.0 / 40320.0);                    // 1/8!
-    pc = fma(pc, x2, 1.0 / 720.0);                       // 1/6!
-    pc = fma(pc, x2, -1.0 / 24.0);                       // 1/4!
-    pc = fma(pc, x2, 0.5);                               // 1/2!
-    *c = fma(-pc, x2, 1.0);
-}
-
-// 6x6 SPD solve, LDL^T with reciprocal pivots (no square roots); false if a pivot is not positive
-__device__ inline bool ldlt_solve6(const double* H, const double* b, double* x) {
-    double L[6][6], d[6], id[6];
-    for (int j = 0; j < 6; ++j) {
-        double s = H[j * 6 + j];
-        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k] * d[k];
-        if (!(s > 0.0)) return false;
-        d[j] = s; id[j] = fast_rcp(s);
-        for (int i = j + 1; i < 6; ++i) {
-            double v = H[i * 6 + j];
-            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
-            L[i][j] = v * id[j];
-        }
-    }
-    double y[6];
-    for (int i = 0; i < 6; ++i) {
-        double s = b[i];
-        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s;
-    }
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i] * id[i];
-        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
-        x[i] = s;
-    }
-    return true;
-}
-
 // Reduced world-frame sums (fold_point) -> H and b at the pose with rotation R (row-major):
 // H_rr = R^T M R, H_rt = R^T N, b_rot = -R^T (sum u x g); S, -sum g, chi2 and the counters are already final.
 // hb_entry gives entry e of the converted row in one fixed operation order, so a block can convert with one lane per
@@ -609,16 +554,11 @@ __device__ __forceinline__ double hb_entry(const double* R, const double* raw, i
     return kind == 0 ? own : kind == 3 ? -v : v;
 }
 
-// ---- the Gauss-Newton step, on one wave.  dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6] (Exp: Rodrigues as
+// ---- the Gauss-Newton step, in the block's first wave.  dx = H^-1 b, R <- R Exp(dx[0:3]), t <- t + dx[3:6] (Exp: Rodrigues as
 // src/slam/reference/math_utils.h:256-269, identity below 1e-7 rad).  It sits on the critical path of every iteration of the
-// single-scan loop (one dependent chain, every block waiting), so it is spread over lanes: lane i < 6 owns row i of the
-// LDL^T factorisation and of the two substitutions, lane e < 9 one entry of Exp and of the new rotation; values cross lanes
-// through v_readlane.  A third of the instructions of the one-lane form and shorter dependent chains; every form of the
-// loop (chained, two launches, batched, sharded) calls this one function, so they all take identical steps.
-__device__ __forceinline__ double bcast(double v, int srclane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
-}
+// single-scan loop (one dependent chain, every block waiting).  Every lane solves the 6x6 system for itself by block
+// elimination (below); lane e < 9 then computes one entry of the new rotation.  Every form of the loop (chained, two
+// launches, batched, sharded, static) calls this one function, so they all take identical steps.
 // all 64 lanes of the wave call it; hb = the 32 converted accumulators (LDS); st may be LDS or global; xch = 36 doubles of
 // LDS the wave may use (the factor's rows are transposed through it for the back substitution)
 __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, double* xch, const SolveParams& sp) {
@@ -627,77 +567,90 @@ __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, doub
         if (lane == 0) { st->status = NDT_ERR_TOO_FEW_POINTS; st->done = 1; }
         return;
     }
-    const int i = lane < 6 ? lane : 5;
-    double h[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int r = i < c ? i : c, cc = i < c ? c : i;
-        h[c] = hb[r * 6 - (r * (r - 1)) / 2 + (cc - r)];        // packed upper triangle, row-major
-    }
-    double y = hb[21 + i];
-    double Lr[6] = {0, 0, 0, 0, 0, 0}, d[6], id[6];
-    double dmin = 1.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {          // column j: pivot on lane j, the entries below it on lanes j + 1 ..
-        double v = h[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v = fma(-Lr[k], bcast(Lr[k] * d[k], j), v);
-        const double dj = bcast(v, j);
-        dmin = (dj > 0.0 && dmin > 0.0) ? dmin : -1.0;      // (a NaN pivot fails too)
-        d[j] = dj; id[j] = fast_rcp(dj);
-        Lr[j] = v * id[j];
-    }
-    if (!(dmin > 0.0)) {                   // (uniform: every pivot is a broadcast)
+    // dx = H^-1 b by block elimination, H = [A B; B^T C] (A: rotation, C: translation block = sum of the information
+    // matrices): C^-1 and the Schur complement's inverse as 3x3 adjugates.  Every lane computes the whole solve for itself
+    // from the 27 numbers in LDS (broadcast reads): ~130 float64 operations with dependent chains a dozen deep and no
+    // cross-lane traffic, against the six pivot-to-pivot round trips (reciprocal, v_readlane broadcasts, an LDS transpose)
+    // of the lane-parallel LDL^T this replaces (3 360 -> see DESIGN.md §5 cycles for the step).  H is positive definite
+    // exactly when C and the Schur complement are (leading minors), which is the failure test.
+    const double A00 = hb[0], A01 = hb[1], A02 = hb[2], A11 = hb[6], A12 = hb[7], A22 = hb[11];
+    const double B00 = hb[3], B01 = hb[4], B02 = hb[5], B10 = hb[8], B11 = hb[9], B12 = hb[10], B20 = hb[12], B21 = hb[13], B22 = hb[14];
+    const double C00 = hb[15], C01 = hb[16], C02 = hb[17], C11 = hb[18], C12 = hb[19], C22 = hb[20];
+    const double r0 = hb[21], r1 = hb[22], r2 = hb[23], r3 = hb[24], r4 = hb[25], r5 = hb[26];
+    // C^-1
+    const double k00 = fma(C11, C22, -(C12 * C12)), k01 = fma(C02, C12, -(C01 * C22)), k02 = fma(C01, C12, -(C02 * C11));
+    const double k11 = fma(C00, C22, -(C02 * C02)), k12 = fma(C01, C02, -(C00 * C12)), k22 = fma(C00, C11, -(C01 * C01));
+    const double detC = fma(C02, k02, fma(C01, k01, C00 * k00));
+    bool spd = C00 > 0.0 && k22 > 0.0 && detC > 0.0;          // (false for NaN)
+    const double iC = fast_rcp(detC);
+    const double i00 = k00 * iC, i01 = k01 * iC, i02 = k02 * iC, i11 = k11 * iC, i12 = k12 * iC, i22 = k22 * iC;
+    // T = B C^-1
+    const double T00 = fma(B02, i02, fma(B01, i01, B00 * i00)), T01 = fma(B02, i12, fma(B01, i11, B00 * i01)), T02 = fma(B02, i22, fma(B01, i12, B00 * i02));
+    const double T10 = fma(B12, i02, fma(B11, i01, B10 * i00)), T11 = fma(B12, i12, fma(B11, i11, B10 * i01)), T12 = fma(B12, i22, fma(B11, i12, B10 * i02));
+    const double T20 = fma(B22, i02, fma(B21, i01, B20 * i00)), T21 = fma(B22, i12, fma(B21, i11, B20 * i01)), T22 = fma(B22, i22, fma(B21, i12, B20 * i02));
+    // S = A - T B^T (symmetric)
+    const double S00 = A00 - fma(T02, B02, fma(T01, B01, T00 * B00)), S01 = A01 - fma(T02, B12, fma(T01, B11, T00 * B10));
+    const double S02 = A02 - fma(T02, B22, fma(T01, B21, T00 * B20)), S11 = A11 - fma(T12, B12, fma(T11, B11, T10 * B10));
+    const double S12 = A12 - fma(T12, B22, fma(T11, B21, T10 * B20)), S22 = A22 - fma(T22, B22, fma(T21, B21, T20 * B20));
+    const double m00 = fma(S11, S22, -(S12 * S12)), m01 = fma(S02, S12, -(S01 * S22)), m02 = fma(S01, S12, -(S02 * S11));
+    const double m11 = fma(S00, S22, -(S02 * S02)), m12 = fma(S01, S02, -(S00 * S12)), m22 = fma(S00, S11, -(S01 * S01));
+    const double detS = fma(S02, m02, fma(S01, m01, S00 * m00));
+    spd = spd && S00 > 0.0 && m22 > 0.0 && detS > 0.0;
+    if (!spd) {                            // (uniform: every lane computed the same numbers)
         if (lane == 0) { st->status = NDT_ERR_SINGULAR; st->done = 1; }
         return;
     }
-    // the factor's rows go to LDS so that lane i can read column i (L[k][i], k > i) for the back substitution
-    if (lane < 6) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) xch[6 * lane + k] = Lr[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {          // L y = b
-        const double yk = bcast(y, k);
-        y = i > k ? fma(-Lr[k], yk, y) : y;
-    }
-    double my_id = id[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) my_id = i == c ? id[c] : my_id;
-    double x = y * my_id;                  // D z = y, then L^T x = z
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    double Lc[6];
-#pragma unroll
-    for (int k = 1; k < 6; ++k) Lc[k] = xch[6 * k + i];          // L[k][i] (used for k > i only)
-#pragma unroll
-    for (int k = 5; k >= 1; --k) {
-        const double xk = bcast(x, k);
-        x = i < k ? fma(-Lc[k], xk, x) : x;
-    }
-    const double dx0 = bcast(x, 0), dx1 = bcast(x, 1), dx2 = bcast(x, 2);
-    const double xx = x * x;               // |dx|^2 = sum over lanes 0..5 (the square root is the host's: it is only reported)
-    const double nrm2 = ((((bcast(xx, 0) + bcast(xx, 1)) + bcast(xx, 2)) + bcast(xx, 3)) + bcast(xx, 4)) + bcast(xx, 5);
+    const double iS = fast_rcp(detS);
+    // x1 = S^-1 (b1 - T b2),  x2 = C^-1 b2 - T^T x1
+    const double w0 = r0 - fma(T02, r5, fma(T01, r4, T00 * r3)), w1 = r1 - fma(T12, r5, fma(T11, r4, T10 * r3)), w2 = r2 - fma(T22, r5, fma(T21, r4, T20 * r3));
+    const double dx0 = fma(m02, w2, fma(m01, w1, m00 * w0)) * iS, dx1 = fma(m12, w2, fma(m11, w1, m01 * w0)) * iS, dx2 = fma(m22, w2, fma(m12, w1, m02 * w0)) * iS;
+    const double u0 = fma(i02, r5, fma(i01, r4, i00 * r3)), u1 = fma(i12, r5, fma(i11, r4, i01 * r3)), u2 = fma(i22, r5, fma(i12, r4, i02 * r3));
+    const double dx3 = u0 - fma(T20, dx2, fma(T10, dx1, T00 * dx0)), dx4 = u1 - fma(T21, dx2, fma(T11, dx1, T01 * dx0)), dx5 = u2 - fma(T22, dx2, fma(T12, dx1, T02 * dx0));
+    const double x = lane == 0 ? dx0 : lane == 1 ? dx1 : lane == 2 ? dx2 : lane == 3 ? dx3 : lane == 4 ? dx4 : dx5;      // lanes 0..5: dx[lane]
+    const double nrm2 = ((((dx0 * dx0 + dx1 * dx1) + dx2 * dx2) + dx3 * dx3) + dx4 * dx4) + dx5 * dx5;
+    (void)xch;
     // new rotation R Exp(dx[0:3]), Exp = I + sin(th) K + (1 - cos(th)) (a a^T - I), K = hat(a), a = dx[0:3] / th:
     // lane e = 3 r + c computes column c of Exp and from it entry (r, c) of the product
     const int e = lane < 9 ? lane : 8, r = e / 3, c = e - 3 * r;
     const double th2 = (dx0 * dx0 + dx1 * dx1) + dx2 * dx2;
     double E0 = c == 0 ? 1.0 : 0.0, E1 = c == 1 ? 1.0 : 0.0, E2 = c == 2 ? 1.0 : 0.0;      // E[m][c], m = 0, 1, 2
     if (th2 > 1e-14) {
-        double ith = __builtin_amdgcn_rsq(th2);            // 1 / th: hardware estimate + two Newton steps
-        ith = ith * fma(-0.5 * th2, ith * ith, 1.5);
-        ith = ith * fma(-0.5 * th2, ith * ith, 1.5);
-        const double th = th2 * ith;
-        const double a0 = dx0 * ith, a1 = dx1 * ith, a2 = dx2 * ith;
-        double sn, cs;
-        step_sincos(th, &sn, &cs);
-        const double c1 = 1.0 - cs;
-        const double ac = c == 0 ? a0 : c == 1 ? a1 : a2;
-        // column c of K = hat(a): c = 0: (0, a2, -a1); c = 1: (-a2, 0, a0); c = 2: (a1, -a0, 0)
-        const double k0 = c == 1 ? -a2 : c == 2 ? a1 : 0.0, k1 = c == 0 ? a2 : c == 2 ? -a0 : 0.0, k2 = c == 0 ? -a1 : c == 1 ? a0 : 0.0;
-        E0 += fma(sn, k0, c1 * (a0 * ac - (c == 0 ? 1.0 : 0.0)));
-        E1 += fma(sn, k1, c1 * (a1 * ac - (c == 1 ? 1.0 : 0.0)));
-        E2 += fma(sn, k2, c1 * (a2 * ac - (c == 2 ? 1.0 : 0.0)));
+        // Exp = I + A hat(phi) + B (phi phi^T - th^2 I) with A = sin(th)/th, B = (1 - cos(th))/th^2: both are series in th^2,
+        // so no square root, no reciprocal and no unit axis on this chain (Taylor to th^18 / th^16 up to 0.64 = 0.8^2:
+        // truncation below 1e-17; beyond, a step of more than 45 degrees, the closed forms)
+        double A, B;
+        if (th2 <= 0.64) {
+            double pa = -1.0 / 121645100408832000.0;           // -1/19!
+            pa = fma(pa, th2, 1.0 / 355687428096000.0);          // 1/17!
+            pa = fma(pa, th2, -1.0 / 1307674368000.0);           // -1/15!
+            pa = fma(pa, th2, 1.0 / 6227020800.0);               // 1/13!
+            pa = fma(pa, th2, -1.0 / 39916800.0);                // -1/11!
+            pa = fma(pa, th2, 1.0 / 362880.0);                   // 1/9!
+            pa = fma(pa, th2, -1.0 / 5040.0);                    // -1/7!
+            pa = fma(pa, th2, 1.0 / 120.0);                      // 1/5!
+            pa = fma(pa, th2, -1.0 / 6.0);                       // -1/3!
+            A = fma(pa, th2, 1.0);
+            double pb = 1.0 / 6402373705728000.0;              // 1/18!
+            pb = fma(pb, th2, -1.0 / 20922789888000.0);          // -1/16!
+            pb = fma(pb, th2, 1.0 / 87178291200.0);              // 1/14!
+            pb = fma(pb, th2, -1.0 / 479001600.0);               // -1/12!
+            pb = fma(pb, th2, 1.0 / 3628800.0);                  // 1/10!
+            pb = fma(pb, th2, -1.0 / 40320.0);                   // -1/8!
+            pb = fma(pb, th2, 1.0 / 720.0);                      // 1/6!
+            pb = fma(pb, th2, -1.0 / 24.0);                      // -1/4!
+            B = fma(pb, th2, 0.5);                               // 1/2!
+        } else {
+            const double th = sqrt(th2);
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            A = sn / th; B = (1.0 - cs) / th2;
+        }
+        const double pc = c == 0 ? dx0 : c == 1 ? dx1 : dx2;
+        // column c of hat(phi): c = 0: (0, p2, -p1); c = 1: (-p2, 0, p0); c = 2: (p1, -p0, 0)
+        const double k0 = c == 1 ? -dx2 : c == 2 ? dx1 : 0.0, k1 = c == 0 ? dx2 : c == 2 ? -dx0 : 0.0, k2 = c == 0 ? -dx1 : c == 1 ? dx0 : 0.0;
+        E0 += fma(A, k0, B * (dx0 * pc - (c == 0 ? th2 : 0.0)));
+        E1 += fma(A, k1, B * (dx1 * pc - (c == 1 ? th2 : 0.0)));
+        E2 += fma(A, k2, B * (dx2 * pc - (c == 2 ? th2 : 0.0)));
     }
     const double Rn = (st->R[3 * r] * E0 + st->R[3 * r + 1] * E1) + st->R[3 * r + 2] * E2;
     const double tn = st->t[lane >= 3 && lane < 6 ? lane - 3 : 0] + x;      // lanes 3..5 hold dx[3..5]
