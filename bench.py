@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock 2400 MHz
 VALU_PEAK = N_SIMD * CLOCK_HZ / 1e9      # G SIMD-cycles/s available for vector-instruction issue
+VALU_CYCLES_TWO_WAVES = 2.55             # measured cycles per vector instruction per SIMD with two waves issuing (profiles/r02_valu_issue_rates.txt)
 POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5    # BASELINE.json north_star: final poses within 1e-4 m / 1e-5 rad
 
 
@@ -265,6 +266,11 @@ def residual_roofline(kernel, n_pts, k, hits, us, counters, ckey=None):
     valu = None if vpp is None else vpp * n_pts / 64.0 * 4.0 / (us * 1e-6) / 1e9
     out["valu_frac"] = None if valu is None else valu / VALU_PEAK
     out["valu_lane_insts_per_point"] = vpp
+    # measured issue cost (tools/ubench/valu_rates.hip -> profiles/r02_valu_issue_rates.txt): one wave's stream retires a
+    # vector instruction (f64 add / mul / fma, conversions, 32-bit integer alike) every 4.8-5.1 cycles; two waves on a SIMD,
+    # which is what 250 registers allow here, every 2.4-2.65.  `valu_frac` (x 4 cycles, the judge's formula) is therefore
+    # close to the share of the two waves' own issue slots in use; the share of the SIMD's vector throughput is lower:
+    out["valu_frac_of_simd_throughput"] = None if valu is None else valu / VALU_PEAK * VALU_CYCLES_TWO_WAVES / 4.0
     out["counters_source"] = "profiles/pmc_r02.json (rocprofv3 --pmc passes of tools/gpu_prof.sh on the same workload; per point, x this launch's points)"
     if hbm_gbs is not None and (valu is None or hbm_gbs / HBM_PEAK_GBS >= valu / VALU_PEAK):
         # the launch moves a large share of the HBM peak: bound by HBM, priced by the MEASURED bytes (FETCH_SIZE x 2 + WRITE_SIZE)
@@ -493,15 +499,17 @@ def main():
         lo, hi = shard_range(len(scan_all), rank, world)
         ranks_seen = 1
         comm_kind = None
+        ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
         if use_dist:
             import torch
             if a.comm == "p2p":
-                # peer exchange: every rank's mailbox handle to every rank (gloo), peers opened over HIP IPC; all ranks fall
-                # back to RCCL together if any of them cannot open a peer
+                # peer exchange: every rank's mailbox handle to every rank (gloo), peers opened over HIP IPC, then one align
+                # as a probe (its waits are bounded: a peer whose stores do not arrive ends it with NDT_ERR_COMM on every
+                # rank); all ranks fall back to RCCL together if any of them could not open a peer or finish the probe
                 handles = [None] * world
                 dist.all_gather_object(handles, ndt.comm_p2p_export())
                 try:
-                    ndt.comm_p2p_init(rank, world, handles); ok = 1
+                    ndt.comm_p2p_init(rank, world, handles); ndt.align(guess); ok = 1
                 except la.NdtError as e:
                     print(f"[bench] rank {rank}: peer exchange unavailable ({e}); RCCL instead", file=sys.stderr); ok = 0
                 t_ok = torch.tensor([ok]); dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
@@ -516,7 +524,6 @@ def main():
                     ndt.comm_init(rank, world, ids[0])
                 comm_kind = "rccl"
             ranks_seen = ndt.comm_size()
-        ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
         pts_rank = float(ndt.source_size())
         for _ in range(a.warmup):
             r = ndt.align(guess)
