@@ -297,7 +297,8 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual(const float* __restri
 // iteration instead of two: the 4 us one-block kernel, its launch gap and its end-of-kernel write-back leave the
 // critical path; the price is ~60 KB of L2 reads and one serial solve per block.  n_prev = 0: no pending step.
 template <int RG> __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* st, const SolveParams& sp, bool do_solve);
-__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]);
+template <class F>
+__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], F&& after_loads);
 
 struct InitPose { double Rt[12]; int use; };
 
@@ -347,22 +348,28 @@ extern "C" int ndt_debug_stamps(unsigned long long* out) { return (int)hipMemcpy
 static_assert(offsetof(GnState, R) == 0 && offsetof(GnState, t) == 72, "InitPose fills the first twelve words of GnState");
 
 template <int K, bool LINKED>
-__global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __restrict__ xs, const float* __restrict__ ys,
-                                                                const float* __restrict__ zs, int n, const int64_t* __restrict__ keys,
-                                                                const VoxSlot* __restrict__ slots, uint32_t mask, const GnState* __restrict__ st_in,
-                                                                GnState* __restrict__ st_out, const double* __restrict__ prev_partials, int n_prev,
+__global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const double* __restrict__ prev_partials, const GnState* __restrict__ st_in,
+                                                                const float* __restrict__ xs, const float* __restrict__ ys,
+                                                                const float* __restrict__ zs, int n, int n_prev, int mode, const int64_t* __restrict__ keys,
+                                                                const VoxSlot* __restrict__ slots, uint32_t mask,
+                                                                GnState* __restrict__ st_out,
                                                                 SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init, PeerWait pw, AosIn aos) {
     static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
     __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
     __shared__ GnState sst;
     STAMP(0);
+    // The first thirteen words of the argument block — everything up to `mode` — arrive in scalar registers with the wave
+    // (kernel-argument preload, Makefile); the point, state and row reads below depend on nothing else, so they are on
+    // their way before the scalar loads of the remaining arguments return.  mode: bit 0 = init.use, bit 1 = aos.p set,
+    // bit 2 = pw.flags set (the structs themselves sit behind those loads).
+    const bool use_init = mode & 1, has_aos = mode & 2, has_pw = mode & 4;
     int i = blockIdx.x * RES1_THREADS + threadIdx.x;
     float xf = 0.f, yf = 0.f, zf = 0.f;
     // (aos.p: the first launch after ndt_set_source_async reads the caller's records and leaves the three-array copy for the
     // launches after it — every point is read by exactly one lane of one block — instead of an unpack kernel in front)
     if (i < n) {
-        if (aos.p) {
+        if (has_aos) {
             const float* r = (const float*)(aos.p + (size_t)i * aos.stride);
             xf = r[0]; yf = r[1]; zf = r[2];
             aos.ox[i] = xf; aos.oy[i] = yf; aos.oz[i] = zf;
@@ -370,12 +377,15 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
     }
     // the state: from st_in, or (first launch of an align) a fresh one at the pose that came as a kernel argument,
     // which saves the host-to-device copy in front of the loop (R[9], t[3] are the first twelve words; the rest is zero)
-    if (threadIdx.x < ST_WORDS)
-        ((double*)&sst)[threadIdx.x] = init.use ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : ((const double*)st_in)[threadIdx.x];
+    double sword = 0.0;
+    if (threadIdx.x < ST_WORDS && !use_init) sword = ((const double*)st_in)[threadIdx.x];       // requested here, stored below
+    auto store_state = [&]() {
+        if (threadIdx.x < ST_WORDS) ((double*)&sst)[threadIdx.x] = use_init ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : sword;
+    };
     bool rows_ok = true;                // (sharded loop: the rows are the ranks' rows in this rank's mailbox, once they are all there)
-    if (n_prev > 0 && pw.flags) rows_ok = peer_gather<16>(pw, prev_partials, sm);      // (ends with a barrier too)
-    else if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm);      // ends with a barrier: sst is complete too
-    else __syncthreads();
+    if (n_prev > 0 && has_pw) { store_state(); rows_ok = peer_gather<16>(pw, prev_partials, sm); }      // (ends with a barrier too)
+    else if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm, store_state);      // ends with a barrier: sst is complete too
+    else { store_state(); __syncthreads(); }
     STAMP(1);
     // (uniform) the rest of the previous step runs in the block's first wave, with no block barrier until the pose is out:
     // column tree, world-frame sums -> H, b (sst still holds the pose the rows were computed at), Gauss-Newton step
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const float* __
         else point_terms<K>(P, xf, yf, zf, keys, slots, mask, ep, acc, &ck);
         i += gridDim.x * RES1_THREADS;
         if (i < n) {
-            if (aos.p) {
+            if (has_aos) {
                 const float* r = (const float*)(aos.p + (size_t)i * aos.stride);
                 xf = r[0]; yf = r[1]; zf = r[2];
                 aos.ox[i] = xf; aos.oy[i] = yf; aos.oz[i] = zf;
@@ -508,7 +518,8 @@ void launch_residual_chain(const float* x, const float* y, const float* z, int n
         for (int j = 0; j < 3; ++j) init.Rt[9 + j] = init_state->t[j];
         init.use = 1;
     }
-#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(x, y, z, n, keys, slots, mask, st_in, st_out, prev_partials, n_prev, sp, ep, partials, init, pw, aos)
+    const int mode = (init.use ? 1 : 0) | (aos.p ? 2 : 0) | (pw.flags ? 4 : 0);
+#define LAUNCH(KK, LL) k_residual_chain<KK, LL><<<grid, RES1_THREADS, 0, s>>>(prev_partials, st_in, x, y, z, n, n_prev, mode, keys, slots, mask, st_out, sp, ep, partials, init, pw, aos)
     if (ep.nearby == 7) { if (linked) LAUNCH(7, true); else LAUNCH(7, false); }
     else LAUNCH(1, false);
 #undef LAUNCH
@@ -695,22 +706,35 @@ __device__ __forceinline__ void row_group_sums(const double* __restrict__ partia
 // row_group_sums<32> on a 512-thread block, same bits: thread (r, c) keeps the sums of row groups r and r + 16 apart and
 // adds them as the tree's first level would (a group's running sum starts at +0 and can never become -0, so the
 // zero padding the 1024-thread form adds is immaterial).  Leaves 16 sums per column: the tree goes on from its second level.
-__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1]) {
+// `after_loads` runs once, after the first (usually the only) batch of row reads has been requested and before any of
+// them is used: work that waits for an earlier read goes there without holding the row reads back.
+template <class F>
+__device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], F&& after_loads) {
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     double va = 0.0, vb = 0.0;
+    bool first = true;
     for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
+        // (all sixteen reads unconditional, from a clamped row, and masked afterwards: no branch between them, one wait)
         double x[8], y[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + 32 * u, j = i + 16;
-            x[u] = i < n_partials ? partials[(size_t)i * ACC_N + c] : 0.0;
-            y[u] = j < n_partials ? partials[(size_t)j * ACC_N + c] : 0.0;
+            x[u] = partials[(size_t)min(i, n_partials - 1) * ACC_N + c];
+            y[u] = partials[(size_t)min(j, n_partials - 1) * ACC_N + c];
+        }
+        if (first) { after_loads(); first = false; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 32 * u, j = i + 16;
+            x[u] = i < n_partials ? x[u] : 0.0;
+            y[u] = j < n_partials ? y[u] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) va += x[u];
 #pragma unroll
         for (int u = 0; u < 8; ++u) vb += y[u];
     }
+    if (first) after_loads();
     sm[r][c] = va + vb;
     __syncthreads();
 }
