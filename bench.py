@@ -579,7 +579,10 @@ def main():
         nr.set_batch_sources(scans)
         pts_step = float(sum(len(scans[s]) for s in pair_scan))
         rsteps = max(5, min(a.steps, 40))
-        for _ in range(3):
+        # (untimed steps until the step time is steady: the first ~15 ms of back-to-back batched launches after the host-side
+        # set-up above run 10-40 % slower — tools/exp_replay.py, 2.0-2.2 then 1.49 ms per step round after round — and three
+        # steps, as before, left that transient inside a 60 ms timed region: 1.52 or 1.67 ms from one run to the next)
+        for _ in range(20):
             r = nr.align_batch_resident(guesses, pair_scan)
         nr.synchronize()
         t0 = time.perf_counter()
