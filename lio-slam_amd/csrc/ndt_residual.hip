@@ -6,9 +6,10 @@
 // (centre + 6 face neighbours), Mahalanobis residual against the 40-byte voxel payload, chi^2 gate.  The
 // per-point sums S = sum Sigma^-1 and g = sum Sigma^-1 e are folded once per point through the 3x6
 // Jacobian J = [-R hat(q) | I] into 21 + 6 accumulators per lane.
-//   memory schedule : all K key reads (16 B = slot s and s+1 of the dense key array) are issued before any is
-//                     used; then all payload reads of the slots that matched; chains longer than two slots
-//                     are finished for all K probes together in one wave-uniform loop.
+//   memory schedule : all K key reads (two 16-byte reads = slots s .. s+3 of the dense key array) are issued before
+//                     any is used; then all payload reads of the slots that matched; chains longer than four slots
+//                     are finished for all K probes together in one wave-uniform loop.  With neighbour links (the
+//                     default) only the point's own cell is hashed: its 64-byte entry carries the six neighbours' slots.
 //   reduction       : lanes -> wave by a butterfly reduce-scatter (32 double exchanges instead of 30 x 6),
 //                     wave -> block through LDS, one 32-double row per block in HBM; every order is fixed.
 // k_reduce_solve adds the rows in a fixed order and takes the Gauss-Newton step on the device, so an iteration
