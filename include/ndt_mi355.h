@@ -75,6 +75,12 @@ typedef struct ndt_config {
      * lio_preinteg.cc:37-38 sets its options).  Both default to 0 = off / PCL's rule. */
     int32_t max_pts_in_voxel;/* > 0: a voxel that already holds more points than this ignores further merges (IncNdt3d freezes at 50) */
     int32_t info_rule;       /* NDT_INFO_EIG_CLAMP (PCL: eigenvalue floor) | NDT_INFO_ADD_1E3 (IncNdt3d: (Sigma + 1e-3 I)^-1; one point: 100 I) */
+    int32_t capacity;        /* > 0: at most capacity - 1 voxels; after a merge the least recently touched ones are dropped
+                              * (IncNdt3d keeps its voxels in an LRU list of capacity_ = 100 000: a point moves its voxel to
+                              * the front, a new voxel evicts the tail).  "Touched" orders voxels by the last cloud that put
+                              * a point into them, then by that point's index in the cloud: the list order IncNdt3d ends a
+                              * cloud with, as long as a cloud does not re-enter a voxel that the same cloud evicted. */
+    int32_t reserved0;       /* keeps the struct's size a multiple of 8 */
 } ndt_config;
 enum { NDT_INFO_EIG_CLAMP = 0, NDT_INFO_ADD_1E3 = 1 };
 

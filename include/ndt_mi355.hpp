@@ -104,6 +104,7 @@ class NormalDistributionsTransform {
     // IncNdt3d's options: freeze voxels beyond n points (0 = never); (Sigma + 1e-3 I)^-1 instead of the eigenvalue floor
     void setMaxPointsPerVoxel(int n) { cfg_.max_pts_in_voxel = n; reconfigure(); }
     void setInformationRule(int rule) { cfg_.info_rule = rule; reconfigure(); }
+    void setVoxelCapacity(int capacity) { cfg_.capacity = capacity; reconfigure(); }   // IncNdt3d capacity_: capacity - 1 voxels kept, least recently touched go
     void setOutlierThreshold(double t) { cfg_.res_outlier_th = t; reconfigure(); }
     const ndt_config& config() const { return cfg_; }
 

@@ -131,6 +131,7 @@ static int check_cfg(const ndt_config* c, std::string& err) {
     if (!(c->eig_floor_ratio > 0.0) || c->eig_floor_ratio > 1.0) { err = "eig_floor_ratio must be in (0,1]"; return NDT_ERR_INVALID_ARG; }
     if (c->max_pts_in_voxel < 0) { err = "max_pts_in_voxel must be >= 0"; return NDT_ERR_INVALID_ARG; }
     if (c->info_rule != NDT_INFO_EIG_CLAMP && c->info_rule != NDT_INFO_ADD_1E3) { err = "unknown info_rule"; return NDT_ERR_INVALID_ARG; }
+    if (c->capacity < 0 || c->capacity == 1) { err = "capacity must be 0 (unbounded) or >= 2 (capacity - 1 voxels are kept)"; return NDT_ERR_INVALID_ARG; }
     return NDT_OK;
 }
 
@@ -175,7 +176,7 @@ void ndt_default_config(ndt_config* c) {
     c->resolution = 1.0f; c->max_iterations = 35; c->eps = 1e-2; c->nearby = 7; c->min_pts_in_voxel = 6;
     c->res_outlier_th = 20.0; c->min_effective_pts = 10; c->key_rule = NDT_KEY_FLOOR_F32; c->eig_floor_ratio = 0.01;
     c->final_eval = 1; c->device = 0;
-    c->max_pts_in_voxel = 0; c->info_rule = NDT_INFO_EIG_CLAMP;
+    c->max_pts_in_voxel = 0; c->info_rule = NDT_INFO_EIG_CLAMP; c->capacity = 0; c->reserved0 = 0;
 }
 
 const char* ndt_version(void) { return "ndt_mi355 0.1 (gfx950)"; }
@@ -249,23 +250,30 @@ int ndt_configure(ndt_handle* h, const ndt_config* cfg) {
     return NDT_OK;
 }
 
+// a map starts (or starts again): empty table, the build parameters of the configuration in force now
+static hipError_t start_map(ndt_handle* h) {
+    hipError_t e = map_clear(h->map, h->stream);
+    if (e != hipSuccess) return e;
+    h->build_cfg.kp = key_params(h->cfg);
+    h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
+    h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
+    h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
+    h->build_cfg.capacity = h->cfg.capacity;
+    return map_track_touch(h->map, h->cfg.capacity > 0, h->stream);
+}
+
 static int merge_common(ndt_handle* h, const void* pts, size_t n, size_t stride, const double T[16], bool reset) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
-    if (reset || !h->have_target) {
-        H_TRY(map_clear(h->map, h->stream));
-        h->build_cfg.kp = key_params(h->cfg);
-        h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
-        h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
-        h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
-    }
+    if (reset || !h->have_target) H_TRY(start_map(h));
     double R[9], t[3];
     if (T) {
         for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; }
     }
     int rc = map_merge_points(h->map, h->work, h->build_cfg, pts, nullptr, nullptr, n, stride, T ? R : nullptr, T ? t : nullptr, h->stream,
                               &h->last_radix_passes, h->err);
+    if (rc == NDT_OK) rc = map_lru_step(h->map, h->work, h->build_cfg, h->stream, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;
 }
@@ -355,17 +363,12 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]) {
     if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
     H_TRY(hipSetDevice(h->cfg.device));
     { int rc = ensure_source_soa(h); if (rc != NDT_OK) return rc; }
-    if (!h->have_target) {
-        H_TRY(map_clear(h->map, h->stream));
-        h->build_cfg.kp = key_params(h->cfg);
-        h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
-        h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
-        h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
-    }
+    if (!h->have_target) H_TRY(start_map(h));
     double R[9], t[3];
     if (T) { for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = T[c * 4 + r]; t[r] = T[12 + r]; } }
     int rc = map_merge_points(h->map, h->work, h->build_cfg, h->sx.p, h->sy.as<float>(), h->sz.as<float>(), h->n_src, 0, T ? R : nullptr,
                               T ? t : nullptr, h->stream, &h->last_radix_passes, h->err);
+    if (rc == NDT_OK) rc = map_lru_step(h->map, h->work, h->build_cfg, h->stream, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;
 }
@@ -780,12 +783,8 @@ int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes) {
     for (size_t i = 0; i < nv * 3; ++i) if (!std::isfinite(m[i])) { h->err = "map blob holds a non-finite mean"; return NDT_ERR_INVALID_ARG; }
     for (size_t i = 0; i < nv * 6; ++i) if (!std::isfinite(cv[i])) { h->err = "map blob holds a non-finite covariance"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
-    H_TRY(map_clear(h->map, h->stream));
+    H_TRY(start_map(h));
     h->have_target = false;
-    h->build_cfg.kp = key_params(h->cfg);
-    h->build_cfg.min_pts = h->cfg.min_pts_in_voxel;
-    h->build_cfg.eig_floor_ratio = h->cfg.eig_floor_ratio;
-    h->build_cfg.max_pts = h->cfg.max_pts_in_voxel; h->build_cfg.info_rule = h->cfg.info_rule;
     int rc = map_restore(h->map, h->work, h->build_cfg, k.data(), c.data(), m.data(), cv.data(), nv, h->stream, h->err);
     if (rc == NDT_OK) h->have_target = true;
     return rc;

@@ -34,6 +34,10 @@ struct VoxelMap {          // the GPU-resident voxel hash
     size_t cap = 0;            // power of two (0 = no map)
     int64_t n_vox = 0;         // voxels that hold points
     int64_t n_entries = 0;     // occupied slots: voxels + ghost cells (what the load factor counts)
+    // ndt_config.capacity > 0 only: [cap] per slot, (cloud number << 32) | index of the cloud's last point in the voxel
+    unsigned long long* touch = nullptr;
+    bool track_touch = false;  // allocate / carry `touch` (set before the table is made)
+    uint32_t cloud_no = 0;     // clouds merged into this map so far
 };
 
 struct SortKeyMap {        // packed key <-> compact radix-sort key for one batch; entry 0 is the most significant axis
@@ -58,6 +62,7 @@ struct MapBuildCfg {
     double eig_floor_ratio;
     int32_t max_pts;         // > 0: voxels holding more points than this are frozen (IncNdt3d)
     int32_t info_rule;       // NDT_INFO_*
+    int32_t capacity;        // ndt_config.capacity (host side only: map_lru_step)
 };
 
 // ---- ndt_map.hip
@@ -70,9 +75,13 @@ struct MapWork {
     int32_t* h_plan_dev = nullptr;   // the same memory as the device addresses it (kernels leave their results there)
     int32_t plan_seq = 0;            // sequence number of the last result requested through the pinned block
     unsigned os_resident = 0;        // tiles of the one-sweep radix pass the device holds at once (0: not asked yet)
+    // the batch map_merge_points saw last, as the device reads it (map_lru_step walks it once more, inside the same call)
+    const unsigned char* last_in = nullptr; const float* last_y = nullptr; const float* last_z = nullptr;
+    size_t last_n = 0, last_stride = 0; int last_has_T = 0; double last_rt[12] = {0};
+    DevBuf sel;                      // radix-select state of map_lru_step: {prefix, k} + 256 digit counts
     void release() {
         if (h_plan) { (void)hipHostFree(h_plan); h_plan = nullptr; h_plan_dev = nullptr; }
-        DevBuf* all[] = {&raw, &tx, &ty, &tz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums};
+        DevBuf* all[] = {&raw, &tx, &ty, &tz, &block_rows, &keys_a, &keys_b, &vals_a, &vals_b, &hist, &flags, &flags2, &segid, &seg_start, &scan_tmp, &misc, &big_pos, &big_list, &big_sums, &sel};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -89,9 +98,13 @@ int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& key
                std::vector<double>& mean, std::vector<double>& cov, std::vector<double>& info,
                std::vector<uint8_t>& valid, hipStream_t s, std::string& err);
 int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>& counts, std::vector<double>& mean, std::vector<double>& cov,
-             hipStream_t s, std::string& err);
+             hipStream_t s, std::string& err, std::vector<unsigned long long>* touch = nullptr);
 int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
-                size_t n, hipStream_t s, std::string& err);
+                size_t n, hipStream_t s, std::string& err, const unsigned long long* touch = nullptr);
+// ndt_config.capacity (IncNdt3d's LRU voxel list): stamps the voxels the last merged batch touched and, once the map holds
+// `capacity` voxels or more, turns the least recently touched ones back into empty cells until capacity - 1 are left
+int map_lru_step(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, hipStream_t s, std::string& err);
+hipError_t map_track_touch(VoxelMap& m, bool on, hipStream_t s);
 
 // ---- PCL compatibility mode (ndt_pcl.hip)
 struct PclEngine {            // what a pass needs from the handle

@@ -44,13 +44,35 @@ hipError_t map_alloc(VoxelMap& m, size_t cap, hipStream_t s) {
     if ((e = hipMalloc((void**)&m.cov, cap * 6 * sizeof(double))) != hipSuccess) return e;
     m.cap = cap;
     m.n_vox = 0; m.n_entries = 0;
+    if (m.track_touch) {
+        if ((e = hipMalloc((void**)&m.touch, cap * sizeof(unsigned long long))) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(m.touch, 0, cap * sizeof(unsigned long long), s)) != hipSuccess) return e;
+    }
     k_init_slots<<<init_slots_grid(cap), 256, 0, s>>>(m.slots, m.keys, m.counts, cap);
     return hipGetLastError();
 }
+// turns the per-slot touch stamps on or off for a map (ndt_config.capacity); an existing table gets a cleared array
+hipError_t map_track_touch(VoxelMap& m, bool on, hipStream_t s) {
+    m.track_touch = on;
+    if (on && !m.touch && m.cap) {
+        hipError_t e;
+        if ((e = hipMalloc((void**)&m.touch, m.cap * sizeof(unsigned long long))) != hipSuccess) return e;
+        return hipMemsetAsync(m.touch, 0, m.cap * sizeof(unsigned long long), s);
+    }
+    if (!on && m.touch) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        e = hipFree(m.touch); m.touch = nullptr;
+        return e;
+    }
+    return hipSuccess;
+}
 // empties the table in place (keeps the allocation: a rebuild of a same-sized map allocates nothing)
 hipError_t map_clear(VoxelMap& m, hipStream_t s) {
+    m.cloud_no = 0;
     if (!m.cap) return hipSuccess;
     m.n_vox = 0; m.n_entries = 0;
+    if (m.touch) { hipError_t e = hipMemsetAsync(m.touch, 0, m.cap * sizeof(unsigned long long), s); if (e != hipSuccess) return e; }
     k_init_slots<<<init_slots_grid(m.cap), 256, 0, s>>>(m.slots, m.keys, m.counts, m.cap);
     return hipGetLastError();
 }
@@ -60,6 +82,7 @@ void map_free(VoxelMap& m) {
     if (m.counts) (void)hipFree(m.counts);
     if (m.mean) (void)hipFree(m.mean);
     if (m.cov) (void)hipFree(m.cov);
+    if (m.touch) (void)hipFree(m.touch);
     m = VoxelMap();
 }
 
@@ -672,7 +695,8 @@ __global__ __launch_bounds__(256) void k_segment_centroid(const uint32_t* seg_st
 // ------------------------------------------------------------------ rehash (capacity growth)
 
 __global__ void k_rehash(const int64_t* ok, const VoxSlot* os, const int32_t* on, const double* om, const double* oc, size_t ocap,
-                         VoxSlot* ns, int64_t* nk, int32_t* nn, double* nm, double* nc, uint64_t nmask) {
+                         VoxSlot* ns, int64_t* nk, int32_t* nn, double* nm, double* nc, uint64_t nmask, const unsigned long long* ot,
+                         unsigned long long* nt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ocap) return;
     const int64_t key = ok[i];
@@ -691,6 +715,7 @@ __global__ void k_rehash(const int64_t* ok, const VoxSlot* os, const int32_t* on
     nn[slot] = on[i];
     for (int j = 0; j < 3; ++j) nm[slot * 3 + j] = om[i * 3 + j];
     for (int j = 0; j < 6; ++j) nc[slot * 6 + j] = oc[i * 6 + j];
+    if (ot) nt[slot] = ot[i];
 }
 
 // ------------------------------------------------------------------ ghost cells and neighbour links
@@ -737,13 +762,16 @@ static size_t pow2_at_least(size_t v) { size_t c = 1024; while (c < v) c <<= 1; 
 static int map_reserve(VoxelMap& m, size_t want_entries, hipStream_t s, std::string& err) {
     size_t need = pow2_at_least(want_entries * 2);       // load factor <= 1/2
     if (m.cap >= need && !(m.n_entries == 0 && m.cap > 16 * need)) return NDT_OK;   // an empty, far too large table is re-made
+    const bool track = m.track_touch;
+    const uint32_t cloud_no = m.cloud_no;
     if (m.n_entries == 0 && m.cap) { HIP_TRY(hipStreamSynchronize(s)); map_free(m); }
     size_t ncap = pow2_at_least(want_entries * 4);        // grow with headroom
     VoxelMap nm;
+    nm.track_touch = track; nm.cloud_no = cloud_no;
     HIP_TRY(map_alloc(nm, ncap, s));
     if (m.cap) {
         k_rehash<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.counts, m.mean, m.cov, m.cap, nm.slots, nm.keys, nm.counts, nm.mean,
-                                                                nm.cov, ncap - 1);
+                                                                nm.cov, ncap - 1, m.touch, nm.touch);
         k_link_all<<<(unsigned)((ncap + 255) / 256), 256, 0, s>>>(nm.keys, nm.slots, ncap);
         HIP_TRY(hipGetLastError());
         nm.n_vox = m.n_vox; nm.n_entries = m.n_entries;
@@ -1713,11 +1741,14 @@ static int map_merge_wide(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const
 int map_merge_points(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const void* pts, const float* soa_y, const float* soa_z, size_t n,
                      size_t stride, const double* R, const double* t, hipStream_t s, int* passes, std::string& err) {
     if (passes) *passes = 0;
+    w.last_n = 0;
     if (n == 0) return map_reserve(m, 1, s, err);
     if (n >= (1ull << 31)) { err = "more than 2^31 points in one batch"; return NDT_ERR_INVALID_ARG; }
     IngestBox box;
     int rc = ingest_bbox(w, cfg.kp, pts, soa_y, soa_z, n, stride, R, t, false, false, s, &box, err);
     if (rc != NDT_OK) return rc;
+    w.last_in = box.d_in; w.last_y = soa_y; w.last_z = soa_z; w.last_n = n; w.last_stride = stride; w.last_has_T = R ? 1 : 0;
+    for (int i = 0; i < 12; ++i) w.last_rt[i] = box.rt.v[i];
     if (box.n_valid == 0) return map_reserve(m, 1, s, err);
     const bool has_invalid = box.n_valid < n;
     if (box.total_bits + (has_invalid ? 1 : 0) > 32) return map_merge_wide(m, w, cfg, pts, soa_y, soa_z, n, stride, R, t, box, s, passes, err);
@@ -1928,7 +1959,7 @@ int map_export(const VoxelMap& m, const KeyParams& kp, std::vector<int64_t>& key
 // map that was saved, and later merges continue from the same statistics.
 __global__ void k_import(const int64_t* in_keys, const int32_t* in_counts, const double* in_mean, const double* in_cov, uint32_t n, MapBuildCfg cfg,
                          VoxSlot* slots, int64_t* keys, int32_t* counts, double* mean, double* cov, uint64_t mask, uint32_t* fresh_flag,
-                         uint32_t* entry_flag) {
+                         uint32_t* entry_flag, const unsigned long long* in_touch, unsigned long long stamp0, unsigned long long* touch) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const int64_t key = in_keys[g];
@@ -1948,10 +1979,11 @@ __global__ void k_import(const int64_t* in_keys, const int32_t* in_counts, const
     for (int j = 0; j < 6; ++j) { cv[j] = in_cov[(size_t)g * 6 + j]; cov[slot * 6 + j] = cv[j]; }
     counts[slot] = in_counts[g];
     finalize_slot(&slots[slot], in_counts[g], mu, cv, cfg);
+    if (touch) touch[slot] = in_touch ? in_touch[g] : stamp0 | (unsigned long long)g;     // (a loaded file: one cloud, in file order)
 }
 
 __global__ void k_export_raw(const int64_t* keys, const int32_t* counts, const double* mean, const double* cov, size_t cap, uint32_t* counter,
-                             int64_t* okeys, int32_t* ocounts, double* omean, double* ocov) {
+                             int64_t* okeys, int32_t* ocounts, double* omean, double* ocov, const unsigned long long* touch, unsigned long long* otouch) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
     if (keys[i] == NDT_KEY_EMPTY || counts[i] == 0) return;
@@ -1959,27 +1991,34 @@ __global__ void k_export_raw(const int64_t* keys, const int32_t* counts, const d
     okeys[o] = keys[i]; ocounts[o] = counts[i];
     for (int j = 0; j < 3; ++j) omean[(size_t)o * 3 + j] = mean[i * 3 + j];
     for (int j = 0; j < 6; ++j) ocov[(size_t)o * 6 + j] = cov[i * 6 + j];
+    if (otouch) otouch[o] = touch[i];
 }
 
 // raw per-voxel state in ascending key order (host vectors)
 int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>& counts, std::vector<double>& mean, std::vector<double>& cov,
-             hipStream_t s, std::string& err) {
+             hipStream_t s, std::string& err, std::vector<unsigned long long>* touch) {
+    if (touch) touch->assign((size_t)m.n_vox, 0ull);
     const size_t nv = (size_t)m.n_vox;
     keys.assign(nv, 0); counts.assign(nv, 0); mean.assign(nv * 3, 0); cov.assign(nv * 6, 0);
     if (!nv) return NDT_OK;
-    DevBuf dcnt, dm, dc, dk, dn;
+    const bool with_touch = touch && m.touch;
+    DevBuf dcnt, dm, dc, dk, dn, dt;
     HIP_TRY(dcnt.ensure(4)); HIP_TRY(dm.ensure(nv * 24)); HIP_TRY(dc.ensure(nv * 48)); HIP_TRY(dk.ensure(nv * 8)); HIP_TRY(dn.ensure(nv * 4));
+    if (with_touch) HIP_TRY(dt.ensure(nv * 8));
     HIP_TRY(hipMemsetAsync(dcnt.p, 0, 4, s));
     k_export_raw<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.counts, m.mean, m.cov, m.cap, dcnt.as<uint32_t>(), dk.as<int64_t>(),
-                                                                 dn.as<int32_t>(), dm.as<double>(), dc.as<double>());
+                                                                 dn.as<int32_t>(), dm.as<double>(), dc.as<double>(), m.touch,
+                                                                 with_touch ? dt.as<unsigned long long>() : nullptr);
     HIP_TRY(hipGetLastError());
     std::vector<int64_t> hk(nv); std::vector<int32_t> hn(nv); std::vector<double> hm(nv * 3), hc(nv * 6);
+    std::vector<unsigned long long> ht(with_touch ? nv : 0);
+    if (with_touch) HIP_TRY(hipMemcpyAsync(ht.data(), dt.p, nv * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hk.data(), dk.p, nv * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hn.data(), dn.p, nv * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hm.data(), dm.p, nv * 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hc.data(), dc.p, nv * 48, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    dcnt.release(); dm.release(); dc.release(); dk.release(); dn.release();
+    dcnt.release(); dm.release(); dc.release(); dk.release(); dn.release(); dt.release();
     std::vector<size_t> ord(nv);
     std::iota(ord.begin(), ord.end(), 0);
     std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
@@ -1988,13 +2027,14 @@ int map_dump(const VoxelMap& m, std::vector<int64_t>& keys, std::vector<int32_t>
         keys[o] = hk[i]; counts[o] = hn[i];
         for (int j = 0; j < 3; ++j) mean[o * 3 + j] = hm[i * 3 + j];
         for (int j = 0; j < 6; ++j) cov[o * 6 + j] = hc[i * 6 + j];
+        if (with_touch) (*touch)[o] = ht[i];
     }
     return NDT_OK;
 }
 
 // the inverse: n voxels (distinct keys, host arrays) into a cleared map
 int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* keys, const int32_t* counts, const double* mean, const double* cov,
-                size_t n, hipStream_t s, std::string& err) {
+                size_t n, hipStream_t s, std::string& err, const unsigned long long* touch) {
     if (n >= (1ull << 31)) { err = "more than 2^31 voxels"; return NDT_ERR_INVALID_ARG; }
     int rc = map_reserve(m, n ? n * 5 / 2 : 1, s, err);      // voxels + their ghost cells at the usual ratio (the ghost stage grows the table if not)
     if (rc != NDT_OK || n == 0) return rc;
@@ -2005,9 +2045,15 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
     HIP_TRY(hipMemcpyAsync(w.vals_a.p, counts, n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(w.keys_b.p, mean, n * 24, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(w.raw.p, cov, n * 48, hipMemcpyHostToDevice, s));
+    const unsigned long long* d_touch = nullptr;
+    if (m.touch && touch) {
+        HIP_TRY(w.sel.ensure(n * 8));
+        HIP_TRY(hipMemcpyAsync(w.sel.p, touch, n * 8, hipMemcpyHostToDevice, s));
+        d_touch = w.sel.as<unsigned long long>();
+    } else if (m.touch) m.cloud_no += 1;          // no stamps came along: the restored voxels count as one cloud, in the order given
     k_import<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(w.keys_a.as<int64_t>(), w.vals_a.as<int32_t>(), w.keys_b.as<double>(), w.raw.as<double>(), (uint32_t)n,
                                                          cfg, m.slots, m.keys, m.counts, m.mean, m.cov, (uint64_t)(m.cap - 1), w.flags.as<uint32_t>(),
-                                                         w.flags2.as<uint32_t>());
+                                                         w.flags2.as<uint32_t>(), d_touch, (unsigned long long)m.cloud_no << 32, m.touch);
     HIP_TRY(hipGetLastError());
     // every key is new (the blob was validated: distinct keys into a cleared map): n voxels, n table entries
     int32_t* plan = w.misc.as<int32_t>();
@@ -2021,4 +2067,120 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
     K.plain = w.keys_a.as<int64_t>(); K.d_count = plan + PL_NSEG;
     PlanWords pw;
     return ghost_stage(m, w, K, (uint32_t)n, PL_NEW_VOX, PL_NEW_ENT, &pw, s, err);
+}
+
+// ------------------------------------------------------------------ voxel capacity (IncNdt3d's LRU list)
+// IncNdt3d keeps its voxels in a list: a point moves its voxel to the front, a new voxel is pushed to the front and the
+// tail is popped when the size reaches capacity_.  After a cloud the list is ordered by the last point that touched each
+// voxel and holds the capacity - 1 most recently touched ones.  Here every slot carries that order as a stamp,
+// (cloud number << 32) | index of the cloud's last point in the voxel, and the cut is made once per merged cloud:
+//   k_touch_points   every point of the batch looks its voxel up and raises the voxel's stamp (integer atomic max: the
+//                    result does not depend on the order of the lanes);
+//   k_sel_*          radix select, most significant byte first, of the k-th smallest stamp among the voxels that hold
+//                    points (k = voxels beyond capacity - 1; stamps are distinct): 8 rounds of a 256-bin count over the
+//                    table and a one-thread pick — no sort, no read-back;
+//   k_evict          voxels at or below that stamp become empty cells again: key and neighbour links stay (the cell is what
+//                    a ghost cell is — DESIGN.md §3 — so no link anywhere has to change), points, statistics and payload go.
+// Evicted cells stay in the table as ghost cells; when those outnumber the voxels eight to one the table is rebuilt from
+// the voxels alone (map_compact: the dump / restore pair of the serialised maps, stamps included).
+
+__global__ __launch_bounds__(256) void k_touch_points(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, RtArg rt,
+                                                      KeyParams kp, const int64_t* keys, uint64_t mask, unsigned long long* touch, unsigned long long stamp0) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float x, y, z;
+        int32_t c[3];
+        if (!load_target_point(raw, soa_y, soa_z, i, stride, has_T, rt.v, kp, x, y, z, c)) continue;
+        const uint32_t slot = table_find(keys, mask, ndt_pack(c[0], c[1], c[2]));
+        if (slot != NDT_LINK_NONE) atomicMax(&touch[slot], stamp0 | (unsigned long long)i);
+    }
+}
+// sel[0] = the stamp's bytes fixed so far (from the top), sel[1] = rank still looked for among the stamps that share them;
+// hist = sel + 2 viewed as 256 counters
+__global__ void k_sel_init(unsigned long long* sel, unsigned long long k) {
+    if (threadIdx.x == 0) { sel[0] = 0ull; sel[1] = k; }
+    ((uint32_t*)(sel + 2))[threadIdx.x] = 0u;
+}
+__global__ __launch_bounds__(256) void k_sel_hist(const int32_t* counts, const unsigned long long* touch, size_t cap, const unsigned long long* sel, int shift,
+                                                  uint32_t* hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sel[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) {
+        if (counts[i] <= 0) continue;
+        const unsigned long long t = touch[i];
+        if (shift < 56 && (t >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+        atomicAdd(&h[(unsigned)(t >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_sel_pick(unsigned long long* sel, int shift) {          // <<<1, 256>>>
+    __shared__ uint32_t h[256];
+    uint32_t* hist = (uint32_t*)(sel + 2);
+    h[threadIdx.x] = hist[threadIdx.x];
+    hist[threadIdx.x] = 0u;                                               // ready for the next round
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = sel[1], below = 0;
+        unsigned d = 255;
+        for (unsigned b = 0; b < 256; ++b) {
+            if (below + h[b] >= k) { d = b; break; }
+            below += h[b];
+        }
+        sel[0] |= (unsigned long long)d << shift;
+        sel[1] = k - below;
+    }
+}
+__global__ __launch_bounds__(256) void k_evict(VoxSlot* slots, int32_t* counts, double* mean, double* cov, unsigned long long* touch, size_t cap,
+                                               const unsigned long long* sel) {
+    const unsigned long long thr = sel[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) {
+        if (counts[i] <= 0 || touch[i] > thr) continue;
+        int32_t* p = (int32_t*)&slots[i];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) p[j] = 0;                            // the 40-byte payload; the six links behind it stay
+        counts[i] = 0; touch[i] = 0ull;
+        for (int j = 0; j < 3; ++j) mean[i * 3 + j] = 0.0;
+        for (int j = 0; j < 6; ++j) cov[i * 6 + j] = 0.0;
+    }
+}
+
+static int map_compact(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, hipStream_t s, std::string& err) {
+    std::vector<int64_t> k; std::vector<int32_t> c; std::vector<double> mu, cv; std::vector<unsigned long long> st;
+    int rc = map_dump(m, k, c, mu, cv, s, err, &st);
+    if (rc != NDT_OK) return rc;
+    if (getenv("NDT_DEBUG_LRU")) fprintf(stderr, "[ndt] table rebuilt from %zu voxels (%lld entries before)\n", k.size(), (long long)m.n_entries);
+    const uint32_t cloud_no = m.cloud_no;
+    HIP_TRY(map_clear(m, s));
+    m.cloud_no = cloud_no;
+    return map_restore(m, w, cfg, k.data(), c.data(), mu.data(), cv.data(), k.size(), s, err, st.data());
+}
+
+int map_lru_step(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, hipStream_t s, std::string& err) {
+    if (cfg.capacity <= 0 || !m.touch || !m.cap) return NDT_OK;
+    m.cloud_no += 1;
+    if (w.last_n) {
+        RtArg rt{};
+        for (int i = 0; i < 12; ++i) rt.v[i] = w.last_rt[i];
+        const unsigned nb = (unsigned)std::min<size_t>(2048, (w.last_n + 255) / 256);
+        k_touch_points<<<nb, 256, 0, s>>>(w.last_in, w.last_y, w.last_z, w.last_n, w.last_stride, w.last_has_T, rt, cfg.kp, m.keys, (uint64_t)(m.cap - 1), m.touch,
+                                          (unsigned long long)m.cloud_no << 32);
+        HIP_TRY(hipGetLastError());
+    }
+    if (m.n_vox < (int64_t)cfg.capacity) return NDT_OK;
+    const unsigned long long k = (unsigned long long)(m.n_vox - ((int64_t)cfg.capacity - 1));
+    HIP_TRY(w.sel.ensure(16 + 256 * 4));
+    unsigned long long* sel = w.sel.as<unsigned long long>();
+    const unsigned nb = (unsigned)std::min<size_t>(1024, (m.cap + 255) / 256);
+    k_sel_init<<<1, 256, 0, s>>>(sel, k);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        k_sel_hist<<<nb, 256, 0, s>>>(m.counts, m.touch, m.cap, sel, shift, (uint32_t*)(sel + 2));
+        k_sel_pick<<<1, 256, 0, s>>>(sel, shift);
+    }
+    k_evict<<<nb, 256, 0, s>>>(m.slots, m.counts, m.mean, m.cov, m.touch, m.cap, sel);
+    HIP_TRY(hipGetLastError());
+    m.n_vox -= (int64_t)k;                        // stamps are distinct (a point lies in one voxel): exactly k voxels went
+    if (m.n_entries > 8 * std::max<int64_t>(m.n_vox, 4096)) return map_compact(m, w, cfg, s, err);
+    return NDT_OK;
 }

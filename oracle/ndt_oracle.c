@@ -61,6 +61,7 @@ typedef struct {
     double cov[6];      /* xx xy xz yy yz zz */
     double pay_off[3];  /* what the residual pass reads (float32-rounded if quantize) */
     double pay_info[6];
+    uint64_t touch;     /* (cloud number << 32) | index of the last point of that cloud that fell into the voxel */
 } ora_voxel;
 
 typedef struct ora_handle {
@@ -77,6 +78,7 @@ typedef struct ora_handle {
     float inv_leaf_f32;
     double inv_res_d, res_d;
     int n_threads;
+    uint32_t cloud_no;  /* clouds merged so far (the LRU order's major key) */
 } ora_handle;
 
 /* ---------------------------------------------------------------- keys */
@@ -262,8 +264,49 @@ static void sort_key_idx(key_idx* a, size_t n) {
     free(b);
 }
 
+/* IncNdt3d's voxel capacity [UPSTREAM-MEM: slam_in_autonomous_driving ch7/ndt_inc.cc AddCloud; SURVEY.md App. B]: voxels
+ * sit in an LRU list, every point moves its voxel to the front, a new voxel is pushed to the front and the tail is
+ * popped when the size reaches capacity_.  At the end of a cloud the list is ordered by "last point that touched the
+ * voxel", and it holds the capacity - 1 most recently touched voxels — as long as the cloud did not come back to a voxel it
+ * had evicted itself (IncNdt3d then dereferences an erased entry; not reproduced).  So: after the merge, drop the least
+ * recently touched voxels until capacity - 1 are left. */
+static int cmp_u64(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+static void evict_lru(ora_handle* h) {
+    const size_t capn = (size_t)h->cfg.capacity;
+    if (h->cfg.capacity <= 0 || h->n_vox < capn) return;
+    const size_t k = h->n_vox - (capn - 1);
+    uint64_t* t = (uint64_t*)malloc(h->n_vox * sizeof(uint64_t));
+    for (size_t v = 0; v < h->n_vox; ++v) t[v] = h->vox[v].touch;
+    qsort(t, h->n_vox, sizeof(uint64_t), cmp_u64);
+    const uint64_t thr = t[k - 1];          /* stamps are distinct: exactly k voxels are at or below it */
+    free(t);
+    size_t w = 0;
+    for (size_t v = 0; v < h->n_vox; ++v)
+        if (h->vox[v].touch > thr) h->vox[w++] = h->vox[v];
+    h->n_vox = w;
+    size_t cap = 1024;
+    while (cap < 2 * (w + 1)) cap *= 2;
+    free(h->slot_key); free(h->slot_vox);
+    h->slot_key = NULL; h->slot_vox = NULL; h->cap = 0;
+    {   /* map_rehash is defined above and rebuilds the slots from vox[] */
+        int64_t* nk = (int64_t*)malloc(cap * sizeof(int64_t));
+        int32_t* nv = (int32_t*)malloc(cap * sizeof(int32_t));
+        for (size_t i = 0; i < cap; ++i) nk[i] = KEY_EMPTY;
+        for (size_t v = 0; v < h->n_vox; ++v) {
+            size_t sl = (size_t)mix64((uint64_t)h->vox[v].key) & (cap - 1);
+            while (nk[sl] != KEY_EMPTY) sl = (sl + 1) & (cap - 1);
+            nk[sl] = h->vox[v].key; nv[sl] = (int32_t)v;
+        }
+        h->slot_key = nk; h->slot_vox = nv; h->cap = cap;
+    }
+}
+
 /* merge `n` float32 world points into the map */
 static int merge_points(ora_handle* h, const float* p, size_t n) {
+    h->cloud_no += 1;
     key_idx* ki = (key_idx*)malloc((n ? n : 1) * sizeof(key_idx));
     size_t m = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -329,9 +372,11 @@ static int merge_points(ora_handle* h, const float* p, size_t n) {
             v->n += nb;
         }
         finalize_voxel(h, &h->vox[vi]);
+        h->vox[vi].touch = ((uint64_t)h->cloud_no << 32) | (uint64_t)ki[e - 1].idx;   /* the stable sort keeps a voxel's points in input order */
         s = e;
     }
     free(ki);
+    evict_lru(h);
     return NDT_OK;
 }
 
@@ -375,6 +420,7 @@ static void map_clear(ora_handle* h) {
     free(h->slot_key); free(h->slot_vox); free(h->vox);
     h->slot_key = NULL; h->slot_vox = NULL; h->vox = NULL;
     h->cap = h->n_vox = h->vox_cap = 0;
+    h->cloud_no = 0;
 }
 void ora_destroy(ora_handle* h) {
     if (!h) return;

@@ -20,7 +20,7 @@ class Config(C.Structure):
         ("nearby", C.c_int32), ("min_pts_in_voxel", C.c_int32), ("res_outlier_th", C.c_double),
         ("min_effective_pts", C.c_int32), ("key_rule", C.c_int32), ("eig_floor_ratio", C.c_double),
         ("final_eval", C.c_int32), ("device", C.c_int32),
-        ("max_pts_in_voxel", C.c_int32), ("info_rule", C.c_int32),
+        ("max_pts_in_voxel", C.c_int32), ("info_rule", C.c_int32), ("capacity", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -59,7 +59,7 @@ def pcl_result_dict(r):
 
 
 def default_config(**kw):
-    cfg = Config(1.0, 35, 1e-2, 7, 6, 20.0, 10, 0, 0.01, 1, 0, 0, 0)
+    cfg = Config(1.0, 35, 1e-2, 7, 6, 20.0, 10, 0, 0.01, 1, 0, 0, 0, 0, 0)
     for k, v in kw.items():
         if not hasattr(cfg, k):
             raise AttributeError(k)

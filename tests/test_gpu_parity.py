@@ -157,6 +157,41 @@ def test_incndt3d_options_parity(mods):
         n.close()
 
 
+def _moving_clouds(seed, n_clouds, pts_per_cloud, step):
+    """a sensor that moves along x: each cloud covers a 12 x 6 x 2 m box whose origin advances `step` m per cloud"""
+    r = np.random.default_rng(seed)
+    return [(r.uniform([0, 0, 0], [12, 6, 2], (pts_per_cloud, 3)) + [step * c, 0, 0]).astype(np.float32) for c in range(n_clouds)]
+
+
+def test_lru_capacity_parity(mods):
+    """`capacity` (IncNdt3d's LRU voxel list): after every merge the engine holds the same capacity - 1
+    voxels with the same statistics as the oracle (whose eviction order is pinned against a point-by-point model of the list
+    in test_oracle_golden.py), evaluates a scan the same, and goes on merging into cells it had dropped.  The last case moves
+    a whole box per cloud for 130 clouds, so the dropped cells pile up and the table is rebuilt from the voxels on the way."""
+    la, synth, Oracle = mods
+    for capacity, step, n_clouds in ((120, 3.0, 9), (60, 5.0, 9), (200, 1.0, 9), (300, 12.0, 130)):
+        clouds = _moving_clouds(11 + capacity, n_clouds, 1500, step)
+        opts = dict(min_pts_in_voxel=3, capacity=capacity)
+        o = Oracle(**opts); n = la.NDT(**opts)
+        o.set_target(clouds[0]); n.set_target(clouds[0])
+        for i, c in enumerate(clouds[1:]):
+            o.add_target(c); n.add_target(c)
+            assert n.num_voxels() == o.num_voxels() <= capacity - 1
+            if n_clouds < 20 or i % 16 == 0 or i == n_clouds - 2:
+                _cmp_maps(n.export_voxels(), o.export_voxels())
+        assert n.num_voxels() == capacity - 1
+        # back over ground that was dropped: the cells are voxels again, from the new points only
+        back = clouds[0] + np.float32(0.013)
+        o.add_target(back); n.add_target(back)
+        _cmp_maps(n.export_voxels(), o.export_voxels())
+        src = clouds[0][:800] + np.float32(0.02)
+        o.set_source(src); n.set_source(src)
+        _cmp_eval(n.eval(np.eye(4)), o.eval(np.eye(4)))
+        n.close()
+    with pytest.raises(la.NdtError):
+        la.NDT(capacity=1)
+
+
 def test_edge_cases(mods):
     la, synth, Oracle = mods
     n = la.NDT()

@@ -202,3 +202,56 @@ def test_incndt3d_options_of_the_oracle():
     assert np.array_equal(merged["counts"], before["counts"] + 40)
     o3.add_target(b); again = o3.export_voxels()          # 70 > 50: frozen now
     assert np.array_equal(again["counts"], merged["counts"]) and np.array_equal(again["cov"], merged["cov"])
+
+
+def _lru_clouds(seed, n_clouds, pts_per_cloud, step):
+    """Clouds of a sensor that moves along x: each covers a 12 x 6 x 2 m box whose origin advances `step` m per cloud,
+    so older voxels fall out of view for good (no cloud re-enters a voxel that it evicted itself)."""
+    r = np.random.default_rng(seed)
+    return [(r.uniform([0, 0, 0], [12, 6, 2], (pts_per_cloud, 3)) + [step * c, 0, 0]).astype(np.float32) for c in range(n_clouds)]
+
+
+def _lru_list_model(clouds, capacity):
+    """IncNdt3d::AddCloud's bookkeeping, point by point (SURVEY.md App. B): an ordered list of voxel keys, a point moves its
+    voxel to the front, a new voxel is pushed to the front and the tail is dropped when the size reaches the capacity.
+    Independent of the oracle: plain Python on the float32 floor rule at 1 m."""
+    from collections import OrderedDict
+    od = OrderedDict()                       # last = front of the list
+    for c in clouds:
+        for p in c:
+            key = tuple(int(v) for v in np.floor(p))
+            if key in od:
+                od.move_to_end(key)
+            else:
+                od[key] = None
+                if len(od) >= capacity:
+                    od.popitem(last=False)
+    return set(od)
+
+
+def test_lru_capacity_of_the_oracle():
+    """`capacity`: after a merge the least recently touched voxels go until capacity - 1 are left — the same set of voxels
+    as the point-by-point LRU list of IncNdt3d keeps, checked against a plain-Python model of that list; the voxels that
+    stay hold the statistics they would hold without a capacity."""
+    from oracle.oracle import Oracle
+    from lio_slam_amd import unpack_keys
+    for capacity, step in ((120, 3.0), (60, 5.0), (200, 1.0)):
+        clouds = _lru_clouds(11 + capacity, 9, 1500, step)
+        o = Oracle(min_pts_in_voxel=3, capacity=capacity, quantize=0)
+        ref = Oracle(min_pts_in_voxel=3, quantize=0)
+        o.set_target(clouds[0]); ref.set_target(clouds[0])
+        for c in clouds[1:]:
+            o.add_target(c); ref.add_target(c)
+        vox, full = o.export_voxels(), ref.export_voxels()
+        want = _lru_list_model(clouds, capacity)
+        got = set(map(tuple, unpack_keys(vox["keys"]).tolist()))
+        assert len(got) == capacity - 1 and got == want
+        # survivors that were never evicted and re-created carry the unbounded map's statistics, bit for bit
+        pos = {int(k): i for i, k in enumerate(full["keys"])}
+        same = 0
+        for i, k in enumerate(vox["keys"]):
+            j = pos[int(k)]
+            if vox["counts"][i] == full["counts"][j]:
+                assert np.array_equal(vox["mean"][i], full["mean"][j]) and np.array_equal(vox["cov"][i], full["cov"][j])
+                same += 1
+        assert same >= (capacity - 1) // 2
