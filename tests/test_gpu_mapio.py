@@ -73,3 +73,28 @@ def test_bad_blobs_are_rejected():
         n.load_map(bytes(nan))
     n.load_map(bytes(blob))                                                # the handle is still usable
     assert n.num_voxels() == a.num_voxels()
+
+
+def test_loaded_map_under_a_voxel_capacity():
+    """A map loaded into a handle with `capacity` counts as one cloud (file order); the next merge cuts it down to
+    capacity - 1 voxels and keeps every voxel the new cloud touched."""
+    import lio_slam_amd as la
+    r = np.random.default_rng(3)
+    first = r.uniform([0, 0, 0], [20, 10, 2], (6000, 3)).astype(np.float32)        # 400 cells
+    a = la.NDT(min_pts_in_voxel=3)
+    a.set_target(first)
+    blob = a.save_map()
+    n_first = a.num_voxels()
+    b = la.NDT(min_pts_in_voxel=3, capacity=150)
+    b.load_map(blob)
+    assert b.num_voxels() == n_first > 150                                  # nothing is dropped by the load itself
+    new = (r.uniform([0, 0, 0], [5, 5, 2], (2000, 3)) + [40, 0, 0]).astype(np.float32)   # 50 cells elsewhere
+    b.add_target(new)
+    assert b.num_voxels() == 149
+    kept = set(map(tuple, la.unpack_keys(b.export_voxels()["keys"]).tolist()))
+    assert {tuple(int(v) for v in np.floor(p)) for p in new} <= kept
+    # of the loaded voxels the ones latest in file order (ascending key) stay
+    old = sorted(k for k in kept if k[0] < 40)
+    want = sorted(map(tuple, la.unpack_keys(np.sort(a.export_voxels()["keys"])[-len(old):]).tolist()))
+    assert old == want
+    a.close(); b.close()
