@@ -208,7 +208,9 @@ int ndt_export_voxels(ndt_handle* h, int64_t* keys, int32_t* counts, double* mea
  * NDT_ERR_CAPACITY when buf != NULL).  ndt_map_load replaces the resident map; the blob's resolution and key_rule
  * must equal the handle's; validity and the float32 payload are derived again under the handle's current
  * min_pts_in_voxel / eig_floor_ratio, so a map loaded under the configuration it was saved with answers bit for bit
- * like the original and later ndt_add_target calls continue from the same statistics. */
+ * like the original and later ndt_add_target calls continue from the same statistics.  The LRU order of
+ * ndt_config.capacity is not stored: a loaded map counts as one cloud whose points came in file (ascending key) order,
+ * and nothing is dropped until the next merge. */
 int ndt_map_save(ndt_handle* h, void* buf, size_t cap_bytes, size_t* n_bytes);
 int ndt_map_load(ndt_handle* h, const void* buf, size_t n_bytes);
 
