@@ -507,8 +507,14 @@ def main():
                 # as a probe (its waits are bounded: a peer whose stores do not arrive ends it with NDT_ERR_COMM on every
                 # rank); all ranks fall back to RCCL together if any of them could not open a peer or finish the probe
                 handles = [None] * world
-                dist.all_gather_object(handles, ndt.comm_p2p_export())
                 try:
+                    mine = ndt.comm_p2p_export()
+                except la.NdtError as e:
+                    print(f"[bench] rank {rank}: no mailbox to export ({e})", file=sys.stderr); mine = None
+                dist.all_gather_object(handles, mine)
+                try:
+                    if any(hd is None for hd in handles):
+                        raise la.NdtError(-1, "a rank exported no mailbox")
                     ndt.comm_p2p_init(rank, world, handles); ndt.align(guess); ok = 1
                 except la.NdtError as e:
                     print(f"[bench] rank {rank}: peer exchange unavailable ({e}); RCCL instead", file=sys.stderr); ok = 0
