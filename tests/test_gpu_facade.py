@@ -9,7 +9,7 @@ import pytest
 from conftest import ROOT, pose_error, rel_err
 
 pytestmark = pytest.mark.gpu
-EXE = os.path.join(ROOT, "lio-slam_amd", "facade_test")
+EXE = os.path.join(ROOT, "lio-slam_amd", os.environ.get("NDT_TEST_EXE_DIR", ""), "facade_test")   # (NDT_TEST_EXE_DIR=asan: the host-ASan builds of tools/build_asan.sh)
 
 
 def test_cpp_facade_matches_oracle(tmp_path):

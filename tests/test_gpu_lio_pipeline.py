@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-EXE = os.path.join(ROOT, "lio-slam_amd", "lio_pipeline_test")
+EXE = os.path.join(ROOT, "lio-slam_amd", os.environ.get("NDT_TEST_EXE_DIR", ""), "lio_pipeline_test")   # (NDT_TEST_EXE_DIR=asan: the host-ASan builds of tools/build_asan.sh)
 LEAF, NEED, ACC_W, GYR_W = 0.2, 1.0, 1e-4, 1e-5
 
 

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT, pose_error
 
 pytestmark = pytest.mark.gpu
-EXE = os.path.join(ROOT, "lio-slam_amd", "odometry_test")
+EXE = os.path.join(ROOT, "lio-slam_amd", os.environ.get("NDT_TEST_EXE_DIR", ""), "odometry_test")   # (NDT_TEST_EXE_DIR=asan: the host-ASan builds of tools/build_asan.sh)
 
 
 def test_frame_loop_matches_oracle(tmp_path):
