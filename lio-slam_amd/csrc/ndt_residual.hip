@@ -571,11 +571,18 @@ __device__ __forceinline__ double hb_entry(const double* R, const double* raw, i
 // single-scan loop (one dependent chain, every block waiting).  Every lane solves the 6x6 system for itself by block
 // elimination (below); lane e < 9 then computes one entry of the new rotation.  Every form of the loop (chained, two
 // launches, batched, sharded, static) calls this one function, so they all take identical steps.
-// all 64 lanes of the wave call it; hb = the 32 converted accumulators (LDS); st may be LDS or global; xch = 36 doubles of
-// LDS the wave may use (the factor's rows are transposed through it for the back substitution)
-__device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, double* xch, const SolveParams& sp) {
+// The step is taken in the WORLD frame, straight from the reduced sums (fold_point): with J = diag(R, I) — orthogonal —
+// H_body = J^T H_w J and b_body = J^T b_w, so dx_body = J^T dx_w, and R Exp(R^T phi_w) = Exp(phi_w) R: the same step
+// and the same norm, without converting 27 numbers through R first (1 060 cycles of this chain, every iteration).  H and b
+// in the caller's frame ([rotation, translation], right perturbation: factor.h:243-251) are only needed when a state is
+// handed back, so st->acc gets them (hb_entry, at the pose the sums were taken at) when the state finishes here.
+// all 64 lanes of the wave call it; raw = the 32 reduced accumulators (LDS); st may be LDS or global
+__device__ __forceinline__ void gn_step_wave(GnState* st, const double* raw, double* xch, const SolveParams& sp) {
     const int lane = threadIdx.x & 63;
-    if ((long long)hb[ACC_NEFF] < (long long)sp.min_effective_pts) {
+    const double* hb = raw;               // H_w = [M N; N^T S] sits in the same slots as the converted row's blocks
+    if ((long long)raw[ACC_NEFF] < (long long)sp.min_effective_pts) {
+        const double v = lane < ACC_N ? hb_entry(st->R, raw, lane) : 0.0;
+        if (lane < ACC_N) st->acc[lane] = v;
         if (lane == 0) { st->status = NDT_ERR_TOO_FEW_POINTS; st->done = 1; }
         return;
     }
@@ -588,7 +595,7 @@ __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, doub
     const double A00 = hb[0], A01 = hb[1], A02 = hb[2], A11 = hb[6], A12 = hb[7], A22 = hb[11];
     const double B00 = hb[3], B01 = hb[4], B02 = hb[5], B10 = hb[8], B11 = hb[9], B12 = hb[10], B20 = hb[12], B21 = hb[13], B22 = hb[14];
     const double C00 = hb[15], C01 = hb[16], C02 = hb[17], C11 = hb[18], C12 = hb[19], C22 = hb[20];
-    const double r0 = hb[21], r1 = hb[22], r2 = hb[23], r3 = hb[24], r4 = hb[25], r5 = hb[26];
+    const double r0 = -hb[21], r1 = -hb[22], r2 = -hb[23], r3 = hb[24], r4 = hb[25], r5 = hb[26];      // b_w = [-(sum u x g); -sum g]
     // C^-1
     const double k00 = fma(C11, C22, -(C12 * C12)), k01 = fma(C02, C12, -(C01 * C22)), k02 = fma(C01, C12, -(C02 * C11));
     const double k11 = fma(C00, C22, -(C02 * C02)), k12 = fma(C01, C02, -(C00 * C12)), k22 = fma(C00, C11, -(C01 * C01));
@@ -609,6 +616,8 @@ __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, doub
     const double detS = fma(S02, m02, fma(S01, m01, S00 * m00));
     spd = spd && S00 > 0.0 && m22 > 0.0 && detS > 0.0;
     if (!spd) {                            // (uniform: every lane computed the same numbers)
+        const double v = lane < ACC_N ? hb_entry(st->R, raw, lane) : 0.0;
+        if (lane < ACC_N) st->acc[lane] = v;
         if (lane == 0) { st->status = NDT_ERR_SINGULAR; st->done = 1; }
         return;
     }
@@ -621,11 +630,11 @@ __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, doub
     const double x = lane == 0 ? dx0 : lane == 1 ? dx1 : lane == 2 ? dx2 : lane == 3 ? dx3 : lane == 4 ? dx4 : dx5;      // lanes 0..5: dx[lane]
     const double nrm2 = ((((dx0 * dx0 + dx1 * dx1) + dx2 * dx2) + dx3 * dx3) + dx4 * dx4) + dx5 * dx5;
     (void)xch;
-    // new rotation R Exp(dx[0:3]), Exp = I + sin(th) K + (1 - cos(th)) (a a^T - I), K = hat(a), a = dx[0:3] / th:
-    // lane e = 3 r + c computes column c of Exp and from it entry (r, c) of the product
+    // new rotation Exp(phi_w) R, Exp = I + sin(th) K + (1 - cos(th)) (a a^T - I), K = hat(a), a = phi_w / th:
+    // lane e = 3 r + c computes ROW r of Exp and from it entry (r, c) of the product
     const int e = lane < 9 ? lane : 8, r = e / 3, c = e - 3 * r;
     const double th2 = (dx0 * dx0 + dx1 * dx1) + dx2 * dx2;
-    double E0 = c == 0 ? 1.0 : 0.0, E1 = c == 1 ? 1.0 : 0.0, E2 = c == 2 ? 1.0 : 0.0;      // E[m][c], m = 0, 1, 2
+    double E0 = r == 0 ? 1.0 : 0.0, E1 = r == 1 ? 1.0 : 0.0, E2 = r == 2 ? 1.0 : 0.0;      // E[r][m], m = 0, 1, 2
     if (th2 > 1e-14) {
         // Exp = I + A hat(phi) + B (phi phi^T - th^2 I) with A = sin(th)/th, B = (1 - cos(th))/th^2: both are series in th^2,
         // so no square root, no reciprocal and no unit axis on this chain (Taylor to th^18 / th^16 up to 0.64 = 0.8^2:
@@ -657,16 +666,21 @@ __device__ __forceinline__ void gn_step_wave(GnState* st, const double* hb, doub
             sincos(th, &sn, &cs);
             A = sn / th; B = (1.0 - cs) / th2;
         }
-        const double pc = c == 0 ? dx0 : c == 1 ? dx1 : dx2;
-        // column c of hat(phi): c = 0: (0, p2, -p1); c = 1: (-p2, 0, p0); c = 2: (p1, -p0, 0)
-        const double k0 = c == 1 ? -dx2 : c == 2 ? dx1 : 0.0, k1 = c == 0 ? dx2 : c == 2 ? -dx0 : 0.0, k2 = c == 0 ? -dx1 : c == 1 ? dx0 : 0.0;
-        E0 += fma(A, k0, B * (dx0 * pc - (c == 0 ? th2 : 0.0)));
-        E1 += fma(A, k1, B * (dx1 * pc - (c == 1 ? th2 : 0.0)));
-        E2 += fma(A, k2, B * (dx2 * pc - (c == 2 ? th2 : 0.0)));
+        const double pc = r == 0 ? dx0 : r == 1 ? dx1 : dx2;
+        // row r of hat(phi): r = 0: (0, -p2, p1); r = 1: (p2, 0, -p0); r = 2: (-p1, p0, 0)
+        const double k0 = r == 1 ? dx2 : r == 2 ? -dx1 : 0.0, k1 = r == 0 ? -dx2 : r == 2 ? dx0 : 0.0, k2 = r == 0 ? dx1 : r == 1 ? -dx0 : 0.0;
+        E0 += fma(A, k0, B * (dx0 * pc - (r == 0 ? th2 : 0.0)));
+        E1 += fma(A, k1, B * (dx1 * pc - (r == 1 ? th2 : 0.0)));
+        E2 += fma(A, k2, B * (dx2 * pc - (r == 2 ? th2 : 0.0)));
     }
-    const double Rn = (st->R[3 * r] * E0 + st->R[3 * r + 1] * E1) + st->R[3 * r + 2] * E2;
+    const double Rn = (E0 * st->R[c] + E1 * st->R[3 + c]) + E2 * st->R[6 + c];
     const double tn = st->t[lane >= 3 && lane < 6 ? lane - 3 : 0] + x;      // lanes 3..5 hold dx[3..5]
     const int it = st->iter + 1;
+    // (uniform) the state finishes with this step: H, b of this iteration in the caller's frame, at the pose they were summed at
+    if (nrm2 < sp.eps * sp.eps || it >= sp.max_iterations) {
+        const double v = lane < ACC_N ? hb_entry(st->R, raw, lane) : 0.0;
+        if (lane < ACC_N) st->acc[lane] = v;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();       // every lane has read the old pose before any lane writes the new one
     if (lane < 9) st->R[lane] = Rn;
@@ -761,13 +775,12 @@ __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* s
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     STAMP(6);
-    double v = 0.0;
-    if (lane < ACC_N) v = hb_entry(st->R, sm[0], lane);
-    if (lane < ACC_N) { sm[1][lane] = v; st->acc[lane] = v; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     STAMP(7);
-    if (do_solve) gn_step_wave(st, sm[1], &sm[2][0], sp);      // rows 2.. are free once the tree has run (36 doubles: sm has >= 4 rows)
+    if (do_solve) gn_step_wave(st, sm[0], &sm[2][0], sp);      // (converts into st->acc itself when the state finishes)
+    else {
+        const double v = lane < ACC_N ? hb_entry(st->R, sm[0], lane) : 0.0;
+        if (lane < ACC_N) st->acc[lane] = v;
+    }
 }
 
 // The first wave leaves a copy of the state in `mirror` (pinned host memory the device can write; nullptr: no copy), so
