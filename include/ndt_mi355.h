@@ -158,16 +158,20 @@ int ndt_add_target_from_source(ndt_handle* h, const double T[16]);
 int ndt_align(ndt_handle* h, const double guess[16], ndt_result* out);
 
 /* ndt_align for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (which has no device memory at all): it is
- * for callers that may not call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid
- * allocation.  The source cloud is handed over as three float32 arrays the caller holds in device memory (x[n], y[n],
- * z[n]; non-finite points are skipped), the map is the handle's resident one, the result goes to *out as in ndt_align.
+ * for callers that may not call hipMalloc — tight serving loops, harnesses that forbid allocation after start-up, code
+ * that runs between the captures of its own HIP graphs.  (It is NOT itself capturable: like ndt_align it returns its result
+ * on the host, so it waits for the handle's stream — hipMemsetAsync + kernels + a bounded poll / hipStreamSynchronize —
+ * before it returns.)  The source cloud is handed over as three float32 arrays the caller holds in device memory (x[n],
+ * y[n], z[n]; non-finite points are skipped), the map is the handle's resident one, the result goes to *out as in ndt_align.
  * The loop's scratch — two buffers of per-block partial rows and two Gauss-Newton states, 132 096 bytes — lives in a
  * file-scope `static __device__` array of the library instead of allocated buffers (every GPU the library runs on holds
- * its own copy until the process ends), so this call makes no hipMalloc / hipFree / allocating library call.
+ * its own copy until the process ends), so this call makes no hipMalloc / hipFree / allocating library call
+ * (tests/test_zz_no_alloc.py: hipMemGetInfo reads the same free bytes before and after).
  *   - n may be at most NDT_STATIC_MAX_POINTS; more is rejected with NDT_ERR_CAPACITY (use ndt_set_source + ndt_align);
  *   - not available on a handle with a communicator (ndt_comm_init) or with profiling enabled: NDT_ERR_INVALID_ARG;
- *   - all calls on one GPU share that GPU's array (also across handles): calls that overlap on one GPU race; serialise
- *     them.  ndt_align and every other entry point keep using the handle's own buffers and are not affected;
+ *   - all calls of a process on one GPU share that GPU's array (also across handles): the library serialises them with a
+ *     per-device lock held for the duration of the call, so handles on several host threads take turns instead of racing.
+ *     ndt_align and every other entry point keep using the handle's own buffers and are not affected;
  *   - on MI355X the launch geometry equals ndt_align's for the same n, so both return the same bits. */
 #define NDT_STATIC_MAX_POINTS (1u << 22)
 int ndt_align_static(ndt_handle* h, const float* d_x, const float* d_y, const float* d_z, size_t n, const double guess[16],

@@ -149,6 +149,7 @@ static __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_B
 #define NDT_MAX_DEVICES 64
 static std::mutex g_scratch_mu;
 static unsigned char* g_scratch_ptr[NDT_MAX_DEVICES];              // per device: resolved once, with that device current
+static std::mutex g_static_call_mu[NDT_MAX_DEVICES];              // per device: one ndt_align_static at a time owns that GPU's array
 // device `dev` must be current
 static hipError_t static_scratch_for_device(int dev, unsigned char** out) {
     if (dev < 0 || dev >= NDT_MAX_DEVICES) return hipErrorInvalidDevice;
@@ -211,6 +212,9 @@ ndt_handle* ndt_create(const ndt_config* cfg) {
         ndt_destroy(h);
         return nullptr;
     }
+    // hipHostMalloc does not clear: the sequence word after the state must not hold a stale number from a destroyed handle's
+    // page (mirror_seq restarts at 1 with every handle)
+    memset(h->h_state, 0, sizeof(GnState) + 64);
     // optional (NDT_NO_MIRROR=1 switches it off): without it the loop copies the state back as before
     if (getenv("NDT_NO_MIRROR") || hipHostGetDevicePointer((void**)&h->h_state_dev, h->h_state, 0) != hipSuccess) h->h_state_dev = nullptr;
     (void)hipGetLastError();
@@ -288,25 +292,30 @@ static int set_source_impl(ndt_handle* h, const void* pts, size_t n, size_t stri
     if ((n && !pts) || stride < 12 || (stride & 3)) { h->err = "bad point buffer (need stride >= 12, multiple of 4)"; return NDT_ERR_INVALID_ARG; }
     if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 source points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
+    const bool on_device = n && points_on_device(pts, h->cfg.device);
+    if (n && stream_ordered && !on_device) { h->err = "ndt_set_source_async takes records in this device's memory"; return NDT_ERR_INVALID_ARG; }
+    // from here on the previous source is gone (its arrays are about to be overwritten, records of an earlier
+    // ndt_set_source_async that nobody unpacked are dropped): a failure below leaves the handle without a source rather than
+    // with a half-replaced one.  src_aos, n_src and have_source are committed together at the end.
+    h->src_aos = nullptr; h->have_source = false; h->n_src = 0;
     H_TRY(h->sx.ensure(n * 4 + 16)); H_TRY(h->sy.ensure(n * 4 + 16)); H_TRY(h->sz.ensure(n * 4 + 16));
+    H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
+    H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
+    const unsigned char* pending = nullptr;
     if (n) {
         // records already in this device's memory are unpacked in place (the unpack kernel is their only reader and has
         // finished when this call returns); host records are staged through sraw
         const void* d_in = pts;
-        const bool on_device = points_on_device(pts, h->cfg.device);
-        if (stream_ordered && !on_device) { h->err = "ndt_set_source_async takes records in this device's memory"; return NDT_ERR_INVALID_ARG; }
         if (!on_device) {
             H_TRY(h->sraw.ensure(n * stride + 16));
             H_TRY(hipMemcpyAsync(h->sraw.p, pts, n * stride, hipMemcpyDefault, h->stream));
             d_in = h->sraw.p;
         }
-        h->src_aos = nullptr;
-        if (stream_ordered) { h->src_aos = (const unsigned char*)d_in; h->src_aos_stride = stride; }      // unpacked by the first launch that reads the source
+        if (stream_ordered) pending = (const unsigned char*)d_in;      // unpacked by the first launch that reads the source
         else H_TRY(unpack_points_soa(d_in, n, stride, h->sx.as<float>(), h->sy.as<float>(), h->sz.as<float>(), h->stream));
-    } else h->src_aos = nullptr;
-    H_TRY(h->partials.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
-    H_TRY(h->partials2.ensure((size_t)residual_grid(n, h->n_cu) * ACC_N * sizeof(double)));
+    }
     if (!stream_ordered) H_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer is free again on return
+    h->src_aos = pending; h->src_aos_stride = stride;
     h->n_src = n;
     h->have_source = true;
     return NDT_OK;
@@ -322,6 +331,9 @@ int ndt_set_source_downsampled(ndt_handle* h, const void* pts, size_t n, size_t 
     if (!(leaf > 0.f) || !isfinite(leaf)) { h->err = "leaf size must be positive"; return NDT_ERR_INVALID_ARG; }
     if (n >= (1ull << 31) - (1ull << 21)) { h->err = "more than 2^31 - 2^21 points (the kernels index points with 32-bit integers)"; return NDT_ERR_INVALID_ARG; }
     H_TRY(hipSetDevice(h->cfg.device));
+    // the source arrays are rewritten below: records of an earlier ndt_set_source_async that nobody unpacked must not be
+    // unpacked over them later (and the old source is gone whether or not this call succeeds)
+    h->src_aos = nullptr; h->have_source = false; h->n_src = 0;
     KeyParams kp;
     kp.inv_leaf_f32 = 1.0f / leaf; kp.inv_res_d = (double)kp.inv_leaf_f32; kp.res_d = (double)leaf; kp.key_rule = NDT_KEY_FLOOR_F32;
     double R[9], t[3];
@@ -676,6 +688,9 @@ int ndt_align_static(ndt_handle* h, const float* d_x, const float* d_y, const fl
     if (h->prof) { h->err = "ndt_align_static does not run with profiling enabled (the event pool allocates)"; return NDT_ERR_INVALID_ARG; }
     if (!h->static_scratch) { h->err = "static scratch not resolved on this device"; return NDT_ERR_HIP; }
     H_TRY(hipSetDevice(h->cfg.device));
+    // the array is shared by every handle on this GPU: calls from several host threads take turns (the call ends
+    // synchronised, so holding the lock for its duration costs nothing); other processes on the GPU have their own copy
+    std::lock_guard<std::mutex> turn(g_static_call_mu[h->cfg.device]);
     // rows of a launch: as ndt_align sizes them, within the scratch's 256 rows (on MI355X the two are the same number,
     // so both entry points sum in the same order and return the same bits)
     const int grid = std::min(residual_grid(n, h->n_cu), STATIC_MAX_ROWS);
@@ -1074,10 +1089,15 @@ int ndt_comm_p2p_export(ndt_handle* h, unsigned char handle_out[NDT_P2P_HANDLE_B
     H_TRY(hipSetDevice(h->cfg.device));
     (void)hipStreamSynchronize(h->stream);
     px_release(h);
-    // fine-grained device memory: peers write it while this device's kernels poll it
+    // fine-grained device memory: peers write it while this device's kernels poll it.  No fallback to plain (coarse-grained)
+    // hipMalloc: stores of a peer into coarse-grained memory need not become visible to a kernel that is already polling,
+    // and the failure would only show as a bounded-wait NDT_ERR_COMM on every align
     if (hipExtMallocWithFlags((void**)&h->px.local, PX_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        H_TRY(hipMalloc((void**)&h->px.local, PX_BYTES));
+        h->px.local = nullptr;
+        h->err = "ndt_comm_p2p_export: fine-grained device memory (hipExtMallocWithFlags, hipDeviceMallocFinegrained) is not available on this "
+                 "device; the peer exchange needs it — use ndt_comm_init (RCCL) instead";
+        return NDT_ERR_COMM;
     }
     H_TRY(hipMemset(h->px.local, 0, PX_BYTES));
     hipIpcMemHandle_t ih;

@@ -1500,6 +1500,9 @@ static hipError_t ensure_plan_host(MapWork& w) {
     if (w.h_plan) return hipSuccess;
     hipError_t e = hipHostMalloc((void**)&w.h_plan, 256, hipHostMallocDefault);
     if (e != hipSuccess) return e;
+    // hipHostMalloc does not clear: a page recycled from a destroyed handle could hold an old sequence word equal to the one
+    // the host is about to wait for (plan_seq restarts at 1 with every handle)
+    memset(w.h_plan, 0, 256);
     if (hipHostGetDevicePointer((void**)&w.h_plan_dev, w.h_plan, 0) != hipSuccess) { (void)hipGetLastError(); w.h_plan_dev = nullptr; }
     return hipSuccess;
 }

@@ -304,12 +304,13 @@ __device__ __forceinline__ void row_group_sums32_on512(const double* __restrict_
 struct InitPose { double Rt[12]; int use; };
 
 // Sharded loop, peer exchange: waits (all threads of the block call it) until every rank's row of all-reduce `seq` has
-// arrived in this rank's mailbox — thread r polls rank r's flag — then adds the rows up in rank order into sm[0] (the
-// other RG - 1 groups are zero, so the column tree that follows returns exactly this sum: every loop form and every rank
-// gets the same bits).  Flags and rows are read with system-scope atomic loads, which bypass the caches: no fence here —
-// a system-scope acquire fence in 230 blocks invalidates the L2 under the residual pass that follows (measured: 112 ->
-// 380 us per align).  Bounded: returns false (uniformly) when a peer never delivers; the caller marks the state
-// NDT_ERR_COMM instead of hanging.
+// arrived in this rank's mailbox — thread r polls rank r's flag (relaxed polls, then one system-scope ACQUIRE load that pairs with the
+// release store the writer put after its rows) — then adds the rows up in rank order into sm[0] (the other RG - 1 groups are zero, so
+// the column tree that follows returns exactly this sum: every loop form and every rank gets the same bits).  The rows are
+// read with system-scope atomic loads, which bypass the caches, after the block barrier that follows the polls.  No
+// system-scope FENCE here: one in 230 blocks invalidates the L2 under the residual pass that follows (measured: 112 ->
+// 380 us per align); the acquire is on the flag load itself.  Bounded: returns false (uniformly) when a peer never
+// delivers; the caller marks the state NDT_ERR_COMM instead of hanging.
 #define PX_SPIN_LIMIT (1 << 21)
 template <int RG>
 __device__ __forceinline__ bool peer_gather(const PeerWait& pw, const double* rows, double (*sm)[ACC_N + 1]) {
@@ -318,10 +319,16 @@ __device__ __forceinline__ bool peer_gather(const PeerWait& pw, const double* ro
     __syncthreads();
     if ((int)threadIdx.x < pw.n) {
         int spins = 0;
+        bool seen = true;
         while (__hip_atomic_load(pw.flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < pw.seq) {
-            if (++spins > PX_SPIN_LIMIT) { s_px_ok = 0; break; }
+            if (++spins > PX_SPIN_LIMIT) { s_px_ok = 0; seen = false; break; }
             __builtin_amdgcn_s_sleep(8);
         }
+        // the polls are relaxed; ONE acquire load of the flag once it has been seen orders the row reads below after the
+        // writer's release store (NDT_PX_NO_ACQUIRE: A/B switch of the build, tools/exp_comm.py)
+#ifndef NDT_PX_NO_ACQUIRE
+        if (seen) (void)__hip_atomic_load(pw.flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     }
     __syncthreads();                        // the flags were seen before any row is requested
     if (threadIdx.x < ACC_N) {

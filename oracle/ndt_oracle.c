@@ -40,7 +40,8 @@
  * mean as a float32 offset from the voxel origin key*res, and the six unique
  * entries of the regularised inverse covariance as float32 (SURVEY.md §8(d):
  * 40-byte payload).  `quantize = 0` keeps them in float64 instead, which is the
- * looser "pure double" cross-check in the tests.
+ * looser "pure double" cross-check in the tests (quantize = 2, 3: fixed-point
+ * offsets, an experiment no engine path uses — see finalize_voxel).
  */
 #include "../include/ndt_mi355.h"
 
@@ -204,7 +205,17 @@ static void jacobi3(const double c[6], double lam[3], double V[3][3]) {
 static int finalize_voxel(const ora_handle* h, ora_voxel* v) {
     v->valid = 0;
     memset(v->pay_info, 0, sizeof v->pay_info);
-    for (int j = 0; j < 3; ++j) v->pay_off[j] = h->quantize ? (double)(float)v->mean_off[j] : v->mean_off[j];
+    for (int j = 0; j < 3; ++j) {
+        if (h->quantize >= 2) {
+            /* EXPERIMENT ONLY (tools/exp_payload_quant.py, DESIGN.md §5 "32-byte payload"): the mean offset as unsigned fixed
+             * point over [-res/2, 3 res/2) with 21 (quantize = 2) or 24 (quantize = 3) bits.  No engine path uses it. */
+            const double scale = h->quantize == 2 ? 1048576.0 : 8388608.0;
+            double r = floor((v->mean_off[j] / h->res_d + 0.5) * scale + 0.5);
+            if (r < 0.0) r = 0.0;
+            if (r > 2.0 * scale - 1.0) r = 2.0 * scale - 1.0;
+            v->pay_off[j] = (r / scale - 0.5) * h->res_d;
+        } else v->pay_off[j] = h->quantize ? (double)(float)v->mean_off[j] : v->mean_off[j];
+    }
     if (v->n < h->cfg.min_pts_in_voxel) return 0;
     if (h->cfg.info_rule == NDT_INFO_ADD_1E3) {
         /* IncNdt3d: info = (Sigma + 1e-3 I)^-1; a single point gets 100 I */

@@ -23,6 +23,12 @@ def mods():
     return la, synth, Oracle
 
 
+@pytest.fixture(scope="module")
+def config2(mods):
+    """BASELINE.json configs[2] at full size (2M-pt map, ~118k-pt scan): generated once for the tests that need it."""
+    return mods[1].make_config(2)
+
+
 def _cmp_maps(g, o):
     assert np.array_equal(g["keys"], o["keys"])               # bit-exact voxel keys
     assert np.array_equal(g["counts"], o["counts"])
@@ -80,10 +86,19 @@ def test_golden_pair(mods, golden, nearby):
     assert e["n_effective"] == int(g[f"neff_{tag}"])
     assert rel_err(e["H"], g[f"H_{tag}"]) < H_TOL
     assert rel_err(e["b"], g[f"b_{tag}"]) < H_TOL
+    # ... and against the PURE float64 vectors (q0: no float32 rounding of the table payload anywhere): the engine's float32
+    # payload moves H, b by 1e-9 ... 4e-8 relative, far inside the north star's 1e-5, and never flips a gate on this pair
+    q0 = f"q0_n{nearby}"
+    assert np.array_equal(la.unpack_keys(keys), g[f"cells_{q0}"]) and np.array_equal(masks, g[f"masks_{q0}"])
+    assert e["n_effective"] == int(g[f"neff_{q0}"])
+    assert rel_err(e["H"], g[f"H_{q0}"]) < H_TOL and rel_err(e["b"], g[f"b_{q0}"]) < H_TOL
+    assert abs(e["chi2"] - float(g[f"chi2_{q0}"])) < H_TOL * abs(float(g[f"chi2_{q0}"]))
     if nearby == 7:
         n.configure(max_iterations=6, eps=0.0, final_eval=0)
         r = n.align(g["guess"])
         dt, dr = pose_error(r["T"], g["poses_q1"][5])
+        assert dt < POSE_T and dr < POSE_R
+        dt, dr = pose_error(r["T"], g["poses_q0"][5])              # the pure-float64 iteration lands at the same pose
         assert dt < POSE_T and dr < POSE_R
 
 
@@ -219,10 +234,58 @@ def test_edge_cases(mods):
         la.NDT(nearby=3)
 
 
-def test_full_size_properties(mods):
+def test_config2_full_size_parity(mods, config2):
+    """BASELINE.json configs[2] — the configuration the headline metric is quoted on — at FULL size against the oracle:
+    the 2M-point map's voxel keys / counts / validity bit-exact (statistics at the usual bars), three keyframe merges of the
+    resident source (ndt_add_target_from_source, process.cc:128-150) compared after each, the cell and gate mask of every one
+    of the ~118k source points bit-exact at the guess and at the truth, H / b within 1e-5, and the 10-iteration
+    fixed-length align bench.py times (eps = 0) within 1e-4 m / 1e-5 rad."""
+    la, synth, Oracle = mods
+    c = config2
+    assert len(c["map"]) == 2_000_000 and len(c["scan"]) > 110_000
+    o = Oracle(); n = la.NDT()
+    o.set_threads(8)
+    o.set_target(c["map"]); n.set_target(c["map"])
+    vg = n.export_voxels()
+    _cmp_maps(vg, o.export_voxels())
+    assert len(vg["keys"]) > 20_000
+    o.set_source(c["scan"]); n.set_source(c["scan"])
+    for T in (c["guess"], c["T_true"]):
+        kg, mg = n.source_cells(T); ko, mo = o.source_cells(T)
+        assert np.array_equal(kg, ko) and np.array_equal(mg, mo)          # 117 593 cells + gate masks, bit-exact
+        _cmp_eval(n.eval(T), o.eval(T))
+    # the bench's align: 10 Gauss-Newton iterations, nothing can stop early
+    o10 = dict(max_iterations=10, eps=0.0, final_eval=0)
+    o.set_params(**o10); n.configure(**o10)
+    rg, ro = n.align(c["guess"]), o.align(c["guess"])
+    assert rg["iterations"] == ro["iterations"] == 10
+    dt, dr = pose_error(rg["T"], ro["T"])
+    assert dt < POSE_T and dr < POSE_R
+    # three keyframes: later scans along the trajectory become the source, are aligned, and join the map at their pose
+    rng = np.random.default_rng(12)
+    npose = len(c["poses"])
+    for k in range(3):
+        T = c["poses"][npose // 2 + 2 + 3 * k].copy(); T[:3, 3] += [0.07 * k, -0.05, 0.0]
+        s = synth.scan(c["scene"], "hdl64", T, rng)
+        o.set_source(s); n.set_source(s)
+        g = T @ synth.perturbation(rng)
+        rg, ro = n.align(g), o.align(g)
+        dt, dr = pose_error(rg["T"], ro["T"])
+        assert dt < POSE_T and dr < POSE_R
+        o.add_target(s, T); n.add_target_from_source(T)
+        _cmp_maps(n.export_voxels(), o.export_voxels())
+    # ... and the map as merged answers the same (cells, masks, H, b) for the original scan
+    o.set_source(c["scan"]); n.set_source(c["scan"])
+    kg, mg = n.source_cells(c["guess"]); ko, mo = o.source_cells(c["guess"])
+    assert np.array_equal(kg, ko) and np.array_equal(mg, mo)
+    _cmp_eval(n.eval(c["guess"]), o.eval(c["guess"]))
+    n.close()
+
+
+def test_full_size_properties(mods, config2):
     """configs[2] at full size (120k-pt scan vs 2M-pt map): size-independent properties."""
     la, synth, Oracle = mods
-    c = synth.make_config(2)
+    c = config2
     n = la.NDT()
     n.set_target(c["map"])
     v1 = n.export_voxels()

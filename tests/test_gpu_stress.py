@@ -282,3 +282,35 @@ def test_stream_ordered_source_gives_the_same_align():
         m0.close(); m1.close()
     finally:
         d.free()
+
+
+def test_pending_async_records_never_overwrite_a_later_source():
+    """ndt_set_source_async leaves records pending; a later call that REPLACES the source without reading it
+    (ndt_set_source_downsampled, ndt_set_source) must drop them: the next align uses the new source, not an unpack of the
+    old caller buffer — which by then may be freed, and is shorter or longer than the new source."""
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    import bench
+    c = synth.make_config(1, small=True)
+    ref = la.NDT(); ref.set_target(c["map"])
+    ref.set_source_downsampled(c["scan"], leaf=0.5)
+    want_src = ref.get_source(); want = ref.align(c["guess"])
+    n = la.NDT(); n.set_target(c["map"])
+    for pending in (c["scan"][: len(c["scan"]) // 8], np.concatenate([c["scan"], c["scan"]])):      # shorter / longer than the new source
+        d = bench.DeviceCloud(pending)
+        n.set_source_async(d.view())
+        n.set_source_downsampled(c["scan"], leaf=0.5)
+        d.free()                                               # the pending records are gone: nothing may read them any more
+        got = n.align(c["guess"])
+        assert n.source_size() == len(want_src) and np.array_equal(n.get_source(), want_src)
+        assert np.array_equal(got["T"], want["T"]) and np.array_equal(got["H"], want["H"]) and got["iterations"] == want["iterations"]
+        # the same with a plain ndt_set_source in between
+        d = bench.DeviceCloud(pending)
+        n.set_source_async(d.view()); n.set_source(want_src); d.free()
+        got = n.align(c["guess"])
+        assert np.array_equal(got["T"], want["T"]) and np.array_equal(got["H"], want["H"])
+    # a failed replacement leaves NO source (not the half-replaced old one)
+    with pytest.raises(la.NdtError):
+        n.set_source_async(c["scan"])                          # host pointer: refused before anything changes
+    assert n.source_size() == len(want_src)
+    n.close(); ref.close()

@@ -31,6 +31,12 @@ class DeviceSoA:
             assert self.hip.hipFree(d) == 0
 
 
+def _free_bytes(hip):
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
 def _same(a, b):
     assert a["rc"] == b["rc"] == 0 and a["iterations"] == b["iterations"] and a["converged"] == b["converged"]
     for k in ("T", "H", "b"):
@@ -51,9 +57,17 @@ def test_align_static_matches_align_on_two_calls_in_a_row():
     n.set_target(c["map"])
     big_d, small_d = DeviceSoA(hip, scan), DeviceSoA(hip, small)
     try:
-        # call 1 (big), call 2 (small) back to back; the references are computed afterwards so nothing runs in between
+        # call 1 (big), call 2 (small) back to back; the references are computed afterwards so nothing runs in between.
+        # "Allocates nothing": the device's free memory (hipMemGetInfo) is the same before, between and after the calls —
+        # a hipMalloc of any size on the path would lower it (the allocator hands out 2 MB-granular pages, nothing is
+        # cached on a path that never allocates), and a warm-up call first makes sure lazily loaded code objects are in
+        n.align_static(small_d.ptr[0].value, small_d.ptr[1].value, small_d.ptr[2].value, small_d.n, c["T_true"])
+        f0 = _free_bytes(hip)
         s1 = n.align_static(big_d.ptr[0].value, big_d.ptr[1].value, big_d.ptr[2].value, big_d.n, c["guess"])
+        f1 = _free_bytes(hip)
         s2 = n.align_static(small_d.ptr[0].value, small_d.ptr[1].value, small_d.ptr[2].value, small_d.n, c["T_true"])
+        f2 = _free_bytes(hip)
+        assert f0 == f1 == f2, ("ndt_align_static changed the device's free memory", f0, f1, f2)
         n.set_source(scan); r1 = n.align(c["guess"])
         n.set_source(small); r2 = n.align(c["T_true"])
         _same(s1, r1); _same(s2, r2)
