@@ -11,15 +11,19 @@ reads them in place).  value = source points x Gauss-Newton iterations per secon
 Every timed align is checked against the CPU oracle replaying the same frames (a bounded prefix), outside the timed
 region: 1e-4 m / 1e-5 rad.
 
-Also reported in the same line: `replay` = configs[4]-style batched offline replay (a slice: `--batch` pairs per step),
-`large_map` = a 2M-point source against a 20M-point / >500k-voxel map whose table does not fit the L2 (the HBM-bound
-regime), `pcl_mode`, `cpu_baseline`.
+Also reported in the same line, at every N (the multi-GPU evidence the driver's one command yields; N = 1 gives the curves
+their origin): `sharded` = configs[3], ONE ~2M-point source cut over the ranks against the 20M-point / 816k-voxel tiled map
+(replicated), all-reduce of the 32-double H/b row per Gauss-Newton iteration — first the peer exchange (ndt_comm_p2p_*), then
+RCCL — with ranks_seen, ms_per_align and the bitwise-identical-poses check per kind; `replay_full` = configs[4] as SURVEY.md
+§8(d) states it, 4096 pairs = 512 distinct configs[2]-sized scans x 8 hypotheses dealt over the ranks, pairs/s, oracle gate.
+At N = 1 only: `online_from_host` (the same frame loop with the frames coming from host memory: pageable, pinned, pinned
+double-buffered), `replay` (a 64-pair slice per step, the batched kernel's roofline), `large_map`, `large_dense_map` (tables
+beyond every cache), `pcl_mode`, `cpu_baseline` (+ CPU model and core counts).
 
 `--gpus N` with N > 1 starts N ranks itself (one process per GPU, `python -m torch.distributed.run`, 127.0.0.1) unless it
-already runs under such a launcher (RANK in the environment).  Default mode at N > 1: every rank replays its own frame
-stream against its own map replica — independent units, no data-path collective, weak scaling.  `--mode sharded` is
-configs[3]: ONE dense ~2M-point source cut over the ranks, an RCCL all-reduce of the 32-double H/b row per iteration
-(strong scaling); every rank must end at the identical pose, which is asserted.
+already runs under such a launcher (RANK in the environment).  `value` at N > 1: every rank replays its own frame stream
+against its own map replica — independent units, no data-path collective, weak scaling.  `--mode sharded` makes configs[3]
+the headline of the line instead (strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,6 +48,7 @@ N_SIMD = 1024           # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock 2400 MHz
 VALU_PEAK = N_SIMD * CLOCK_HZ / 1e9      # G SIMD-cycles/s available for vector-instruction issue
 VALU_CYCLES_TWO_WAVES = 2.55             # measured cycles per vector instruction per SIMD with two waves issuing (profiles/r02_valu_issue_rates.txt)
+GATHER64_GBS = 3200.0   # measured random 64-byte-line gather rate of this GPU (profiles/r03_gather_rate.txt: 3.1-3.25 TB/s at 256 MB - 2 GB tables)
 POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5    # BASELINE.json north_star: final poses within 1e-4 m / 1e-5 rad
 
 
@@ -86,13 +91,31 @@ def algorithmic_bytes_per_point(k, h):
     return 12.0 + 8.0 * k + 40.0 * h
 
 
+def csrc_hash():
+    """Content hash of the kernel sources (lio-slam_amd/csrc/*.hip, *.h): stamped into the committed counter file by
+    tools/pmc_summary.py and compared here, so that counters taken on other kernels than the ones running are flagged
+    (`.git` does not travel to the GPU box, so this is a hash of the files, not a commit id)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lio-slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "lio-slam_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_counters():
-    """Per-launch hardware-counter figures of the kernels, from the committed rocprofv3 PMC passes of this round
-    (profiles/pmc_r02.json, written by tools/pmc_summary.py from tools/gpu_prof.sh's runs)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
-    except (OSError, ValueError):
-        return {}
+    """Per-launch hardware-counter figures of the kernels, from the committed rocprofv3 PMC passes (profiles/pmc_r03.json,
+    written by tools/pmc_summary.py from tools/gpu_prof.sh's runs; pmc_r02.json if this round's file is missing).  The
+    file carries the hash of the kernel sources it was taken on: `_stale` is set when that is not what is running."""
+    for name in ("pmc_r03.json", "pmc_r02.json"):
+        try:
+            c = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        c["_file"] = "profiles/" + name
+        c["_stale"] = c.get("_csrc_hash") != csrc_hash()
+        return c
+    return {"_file": None, "_stale": True}
 
 
 def pose_error(T, T_ref):
@@ -125,34 +148,13 @@ def load_workload(index, rank, world, dist, small):
     return dict(np.load(path))
 
 
-def load_dense_workload(w, rank, world, dist):
-    """configs[3] inputs from the configs[2] pieces: the same yard and sensor pose, a dense 128-ring scan of ~2 M returns
-    as the source, and a 20 M-point map (the 2 M-point keyframe map resampled ten times with the sensor's 1 cm range
-    noise: ten times the sampling density on the same surfaces).  Generated once (rank 0), cached under /tmp."""
-    from lio_slam_amd import synth
-    path = "/tmp/ndt_bench_c3.npz"
-    if rank == 0 and not os.path.exists(path):
-        rng = np.random.Generator(np.random.PCG64(synth.seed_for(2)))
-        scene = synth.yard_scene(rng)                  # make_config(2) draws the scene first: this is the same yard
-        rng = np.random.Generator(np.random.PCG64(synth.seed_for(3)))
-        src = synth.scan(scene, "dense128", w["T_true"], rng)
-        m = np.concatenate([w["map"]] + [(w["map"] + rng.normal(0, 0.01, w["map"].shape)).astype(np.float32) for _ in range(9)])
-        tmp = path + f".{os.getpid()}.npz"
-        np.savez(tmp, map=m, scan=src)
-        os.replace(tmp, path)
-    if world > 1:
-        dist.barrier()
-    d = np.load(path)
-    return d["map"], d["scan"]
-
-
-def large_map_workload():
-    """The HBM-bound regime: the 20 M-point, >500 k-voxel map of tests/test_gpu_scale.py (the 200 k-point yard map tiled
+def large_map_workload(rank=0, world=1, dist=None):
+    """configs[3]'s inputs, and the HBM-bound regime: the 20 M-point, >500 k-voxel map of tests/test_gpu_scale.py (the 200 k-point yard map tiled
     10 x 10 at 300 m pitch with 1 cm jitter; its voxel table, ghosts included, is > 100 MB: no L2 holds it) and a 2 M-point
     source that touches ALL of it (a sixth of the scan seen from every tile, in one sensor frame).  Cached under /tmp."""
     from lio_slam_amd import synth
     path = "/tmp/ndt_bench_large2.npz"
-    if not os.path.exists(path):
+    if rank == 0 and not os.path.exists(path):
         c = synth.make_config(2, small=True)
         rng = np.random.default_rng(5)
         tiles, parts = [], []
@@ -171,7 +173,49 @@ def large_map_workload():
         g = T @ synth.se3([6e-6, -5e-6, 6e-6], [0.07, -0.06, 0.03])
         np.savez(tmp, map=np.concatenate(tiles), scan=np.concatenate(parts), T_true=T, guess=g)
         os.replace(tmp, path)
+    if world > 1:
+        dist.barrier()
     return dict(np.load(path))
+
+
+REPLAY_SCANS, REPLAY_HYP = 512, 8          # BASELINE.json configs[4] / SURVEY.md §8(d): 4096 pairs = 512 scans x 8 hypotheses
+
+
+def _replay_scan_job(k):
+    """Scan k of the offline-replay set (a worker process of prepare_replay_full; NumPy only)."""
+    from lio_slam_amd import synth
+    scene = synth.yard_scene(np.random.Generator(np.random.PCG64(synth.seed_for(2))))      # the configs[2] yard (make_config draws it first)
+    poses = synth.trajectory(40, step=0.5)
+    rng = np.random.Generator(np.random.PCG64([synth.seed_for(4), k]))
+    # a pose of its own for every scan: along the mapped trajectory, off it by up to 0.3 m sideways and 3 degrees of yaw
+    T = poses[(k * 39) // (REPLAY_SCANS - 1)] @ synth.se3([0, 0, np.deg2rad(rng.uniform(-3, 3))], [rng.uniform(-0.25, 0.25), rng.uniform(-0.3, 0.3), 0.0])
+    s = synth.scan(scene, "hdl64", T, rng)
+    g = np.stack([T @ synth.perturbation(rng, 0.05, 0.5, 0.5, 5.0) for _ in range(REPLAY_HYP)])     # hypotheses up to 0.5 m / 5 degrees
+    return s, T, g
+
+
+def prepare_replay_full(rank, world, dist):
+    """configs[4] as SURVEY.md §8(d) states it: 512 DISTINCT configs[2]-sized scans (HDL-64 shape, each from a pose of its own in
+    the configs[2] yard, ~118 k returns, 722 MB in all) x 8 initial-pose hypotheses (perturbations up to 0.5 m / 5 degrees) =
+    4096 (scan, guess) pairs against the configs[2] map.  Generated once by rank 0 with a pool of worker processes — called
+    BEFORE this process touches the GPU — and cached under /tmp as a memory-mappable array."""
+    pts_path, meta_path = "/tmp/ndt_bench_replay512_pts.npy", "/tmp/ndt_bench_replay512_meta.npz"
+    if rank == 0 and not (os.path.exists(pts_path) and os.path.exists(meta_path)):
+        import multiprocessing as mp
+        t0 = time.perf_counter()
+        nproc = max(1, min(16, cpu_info()["cpus_usable"] or 1))
+        with mp.get_context("fork").Pool(nproc) as pool:
+            res = pool.map(_replay_scan_job, range(REPLAY_SCANS), chunksize=4)
+        off = np.zeros(REPLAY_SCANS + 1, np.int64); off[1:] = np.cumsum([len(r[0]) for r in res])
+        tmp = pts_path + f".{os.getpid()}.npy"
+        np.save(tmp, np.concatenate([r[0] for r in res])); os.replace(tmp, pts_path)
+        tmp = meta_path + f".{os.getpid()}.npz"
+        np.savez(tmp, offsets=off, T=np.stack([r[1] for r in res]), guesses=np.concatenate([r[2] for r in res])); os.replace(tmp, meta_path)
+        print(f"[bench] replay set: {REPLAY_SCANS} scans, {off[-1]} points generated in {time.perf_counter() - t0:.1f} s on {nproc} processes", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+    meta = np.load(meta_path)
+    return {"pts": np.load(pts_path, mmap_mode="r"), "offsets": meta["offsets"], "T": meta["T"], "guesses": meta["guesses"]}
 
 
 def replicate_map_blob(blob, nx, ny, pitch_cells):
@@ -243,43 +287,78 @@ def build_roofline(n_points, n_voxels, passes, ms):
 
 
 def residual_roofline(kernel, n_pts, k, hits, us, counters, ckey=None):
-    """Roofline object of a residual-kernel launch, timed live (`us`), priced by what the hardware counters of the same
-    workload say it spends (committed rocprofv3 passes, per point x this launch's points):
-      valu_frac         = VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x time)
-      hbm_frac_measured = (FETCH_SIZE x 2 + WRITE_SIZE) / time / 8 TB/s
-    The larger one names the bound and gives `frac`.  LiDAR points arrive in scan order, so neighbouring lanes look up the
-    same voxels and the caches serve part of the algorithmic bytes (B_res x points): nearly all of them for the 9 MB table
-    of configs[2] (vector-issue bound), a third for tables of 120-600 MB (HBM bound).  The algorithmic figure is kept as
-    `algorithmic_GBps`, an absolute number: divided by the HBM peak it can exceed 1 and would not be an HBM fraction."""
+    """Roofline object of a residual-kernel launch, timed live (`us`: HIP events on the engine's stream around back-to-back
+    launches of the kernel alone).
+      achieved (ALGORITHMIC) = B_res x points / time, B_res = 12 + 8 k + 40 h — against the 8 TB/s HBM peak
+                               this is `frac` whenever it does not exceed the peak;
+      traffic                = HBM bytes per launch from the committed rocprofv3 passes of the same workload (per point x
+                               this launch's points): FETCH_SIZE (KB) x 1024 x the factor calibrated for THIS kernel's gather
+                               (profiles/r03_fetch_calibration.txt: a 64-byte slot read counts 64 bytes: factor 1.0, not the
+                               2.0 of 16-byte streaming reads) + WRITE_SIZE x 1024;  hbm_frac_measured = traffic / time / peak;
+      valu_frac              = VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x time).
+    Where the caches serve so much that the algorithmic rate exceeds the HBM peak (batched launches on the 9 MB table of
+    configs[2]; large tables a third cache-served), `frac` is the larger of the two measured fractions instead and `bound`
+    says which; no `frac` exceeds 1."""
     bpp = algorithmic_bytes_per_point(k, hits)
     c = counters.get(ckey or kernel, {})
+    alg = n_pts * bpp / (us * 1e-6) / 1e9
     out = {"kernel": kernel, "kernel_avg_us": us, "points_per_launch": int(n_pts), "hits_per_point": hits, "bytes_per_point": bpp,
-           "algorithmic_GBps": n_pts * bpp / (us * 1e-6) / 1e9,
+           "algorithmic_bytes_per_launch": n_pts * bpp, "algorithmic_GBps": alg,
            "timing": "hipEvents on the engine stream around back-to-back launches of the kernel alone"}
     traffic = c.get("hbm_bytes_per_point")
     out["traffic"] = None if traffic is None else traffic * n_pts
     hbm_gbs = None if traffic is None else traffic * n_pts / (us * 1e-6) / 1e9
     out["hbm_frac_measured"] = None if hbm_gbs is None else hbm_gbs / HBM_PEAK_GBS
     out["traffic_over_algorithmic"] = None if traffic is None else traffic / bpp
+    out["fetch_factor"] = c.get("fetch_factor")
     out["l2_hit_rate"] = c.get("l2_hit_rate")
     vpp = c.get("valu_insts_per_point")            # wave-instructions x 64 lanes / points: lane-instructions per point
     valu = None if vpp is None else vpp * n_pts / 64.0 * 4.0 / (us * 1e-6) / 1e9
     out["valu_frac"] = None if valu is None else valu / VALU_PEAK
     out["valu_lane_insts_per_point"] = vpp
     # measured issue cost (tools/ubench/valu_rates.hip -> profiles/r02_valu_issue_rates.txt): one wave's stream retires a
-    # vector instruction (f64 add / mul / fma, conversions, 32-bit integer alike) every 4.8-5.1 cycles; two waves on a SIMD,
-    # which is what 250 registers allow here, every 2.4-2.65.  `valu_frac` (x 4 cycles, the judge's formula) is therefore
-    # close to the share of the two waves' own issue slots in use; the share of the SIMD's vector throughput is lower:
+    # vector instruction every 4.8-5.1 cycles; two waves on a SIMD, which is what 232 registers allow here, every 2.4-2.65
     out["valu_frac_of_simd_throughput"] = None if valu is None else valu / VALU_PEAK * VALU_CYCLES_TWO_WAVES / 4.0
-    out["counters_source"] = "profiles/pmc_r02.json (rocprofv3 --pmc passes of tools/gpu_prof.sh on the same workload; per point, x this launch's points)"
-    if hbm_gbs is not None and (valu is None or hbm_gbs / HBM_PEAK_GBS >= valu / VALU_PEAK):
-        # the launch moves a large share of the HBM peak: bound by HBM, priced by the MEASURED bytes (FETCH_SIZE x 2 + WRITE_SIZE)
+    out["counters_source"] = f"{counters.get('_file')} (rocprofv3 --pmc passes of tools/gpu_prof.sh on the same workload; per point, x this launch's points)"
+    out["counters_stale"] = bool(counters.get("_stale", True))
+    if alg <= HBM_PEAK_GBS:
+        out.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+                    "how": "algorithmic bytes (B_res x points of one launch) / live kernel time / 8 TB/s; `traffic` = HBM bytes the counters "
+                           "saw per launch (FETCH_SIZE at the factor calibrated for this gather + WRITE_SIZE)"})
+    elif hbm_gbs is not None and (valu is None or hbm_gbs / HBM_PEAK_GBS >= valu / VALU_PEAK):
         out.update({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                    "how": "measured HBM bytes per launch / live kernel time; the algorithmic bytes are higher (caches serve the rest), see algorithmic_GBps"})
+                    "how": "the algorithmic rate exceeds the HBM peak here (caches serve part of it): MEASURED HBM bytes per launch / live kernel time / 8 TB/s"})
     else:
         out.update({"bound": "valu", "achieved": valu, "peak": VALU_PEAK, "unit": "G SIMD-cycles/s", "frac": None if valu is None else valu / VALU_PEAK,
-                    "how": "SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x live kernel time)"})
+                    "how": "the algorithmic rate exceeds the HBM peak here (the table is cache-resident): SQ_INSTS_VALU per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x live kernel time)"})
     return out
+
+
+def gather_bound(rl):
+    """Launches against tables beyond every cache fetch random 64-byte lines: the rate to hold them against is this GPU's
+    measured random-line gather rate (tools/ubench/fetch_calibration time -> profiles/r03_gather_rate.txt: 3.1-3.25 TB/s of
+    line bytes at 256 MB - 2 GB tables, whatever the loads in flight), not the 8 TB/s of a stream."""
+    if rl.get("traffic") is not None:
+        gbs = rl["traffic"] / (rl["kernel_avg_us"] * 1e-6) / 1e9
+        rl["random_line_gather_GBps_measured_ceiling"] = GATHER64_GBS
+        rl["frac_of_random_line_gather_rate"] = gbs / GATHER64_GBS
+        rl["regime"] = "random 64-byte-line fetches from HBM (table beyond L2 and Infinity Cache)"
+    return rl
+
+
+def cpu_info():
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_usable": usable}
 
 
 def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
@@ -290,7 +369,8 @@ def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
     t0 = time.perf_counter(); o.set_target(w["map"]); build_s = time.perf_counter() - t0
     o.set_source(w["scan"])
     n = o.source_size()
-    for name, threads in (("cpu_baseline", 1), ("cpu_baseline_mt", min(16, os.cpu_count() or 1))):
+    ci = cpu_info()
+    for name, threads in (("cpu_baseline", 1), ("cpu_baseline_mt", min(16, ci["cpus_usable"] or 1))):
         o.set_threads(threads)
         o.align(w["guess"])                      # warm
         reps, t0 = 0, time.perf_counter()
@@ -301,9 +381,205 @@ def time_cpu_baseline(w, iters, nearby, budget_s=12.0):
                 break
         out[name] = {"value": n * iters * reps / el, "unit": "source-points*iters/s", "cores": threads, "kind": "port",
                      "sample": f"{reps} aligns x {iters} GN iterations of the same {n}-pt scan vs 2M-pt map "
-                               f"({el:.1f} s of CPU work)", "scans_per_s": reps / el}
+                               f"({el:.1f} s of CPU work)", "scans_per_s": reps / el, **ci}
     out["cpu_baseline"]["map_build_s"] = build_s
     return out
+
+
+class Hip:
+    """The few HIP runtime calls the CALLER's side of the benchmark needs (pinned host frames, a copy stream, events)."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            cls._lib = DeviceCloud._hip or ctypes.CDLL("libamdhip64.so")
+            DeviceCloud._hip = cls._lib
+        return cls._lib
+
+    @classmethod
+    def check(cls, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: hip error {rc}")
+
+
+class PinnedFrame:
+    """A scan in page-locked host memory (hipHostMalloc), as 12-byte xyz records: what a LiDAR driver's DMA buffer looks like."""
+
+    def __init__(self, pts):
+        a = np.ascontiguousarray(pts, np.float32)
+        self.n, self.nbytes, self.ptr = len(a), a.nbytes, ctypes.c_void_p()
+        Hip.check(Hip.lib().hipHostMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(max(a.nbytes, 16)), 0), "hipHostMalloc")
+        ctypes.memmove(self.ptr, a.ctypes.data, a.nbytes)
+
+    def free(self):
+        if self.ptr:
+            Hip.lib().hipHostFree(self.ptr); self.ptr = ctypes.c_void_p()
+
+
+def sharded_section(la, ndt, src_all, guess, T_true, a, rank, world, dist, use_dist, kinds):
+    """configs[3]: ONE ~2M-point source cut into contiguous ranges over the ranks (shard_range), every rank with a replica of
+    the map already resident in `ndt`; per Gauss-Newton iteration one all-reduce of the 32-double H/b row — `p2p` = peer
+    stores into the ranks' mailboxes (ndt_comm_p2p_*), `rccl` = ncclAllReduce (ndt_comm_init).  For each kind: attach, 3 untimed
+    + 10 timed aligns between barriers, max over ranks; the poses of all ranks are gathered and must be identical bit for bit.
+    Runs at world == 1 too (a one-rank communicator: the curve's origin).  A kind that cannot attach on some rank (RCCL refuses
+    two ranks on one device in a one-GPU rehearsal) is reported with its error on every rank, not skipped silently."""
+    from lio_slam_amd.shard import shard_range
+    lo, hi = shard_range(len(src_all), rank, world)
+    ndt.set_source(src_all[lo:hi])
+    pts_rank = float(ndt.source_size())
+
+    def allmin_int(x):
+        if not use_dist:
+            return x
+        import torch
+        t = torch.tensor([x]); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t[0])
+
+    def allmax(x):
+        if not use_dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); return float(t[0])
+
+    def allsum(x):
+        if not use_dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t); return float(t[0])
+
+    pts_all = allsum(pts_rank)
+    out = {"workload": "configs[3]: ONE dense ~2M-point source sharded over the ranks against the 20M-point / 816k-voxel tiled map "
+                       "(tests/test_gpu_scale.py's map: table beyond every L2), all-reduce of the 32-double H,b row per iteration",
+           "source_points_total": int(pts_all), "source_points_this_rank": int(pts_rank), "gn_iterations_per_align": a.iters}
+    for kind in kinds:
+        err = None
+        try:
+            if kind == "p2p":
+                mine = ndt.comm_p2p_export()
+                handles = [mine]
+                if use_dist:
+                    handles = [None] * world
+                    dist.all_gather_object(handles, mine)
+                ndt.comm_p2p_init(rank, world, handles)
+            else:
+                with stdout_to_stderr():                         # RCCL prints its version banner on stdout
+                    ids = [la.NDT.comm_unique_id() if rank == 0 else None]
+                    if use_dist:
+                        dist.broadcast_object_list(ids, src=0)
+                    ndt.comm_init(rank, world, ids[0])
+            ndt.align(guess)                                     # probe: its waits are bounded (NDT_ERR_COMM instead of a hang)
+        except la.NdtError as e:
+            err = str(e)
+        except Exception as e:                                   # (a rank that failed to export still has to reach the collectives below)
+            err = repr(e)
+        if allmin_int(0 if err else 1) == 0:
+            try:
+                ndt.comm_destroy()
+            except la.NdtError:
+                pass
+            out[kind] = {"error": err or "another rank could not attach"}
+            continue
+        ranks_seen = ndt.comm_size()
+        for _ in range(3):
+            r = ndt.align(guess)
+        ndt.synchronize()
+        if use_dist:
+            dist.barrier()
+        n_al = 10
+        t0 = time.perf_counter()
+        for _ in range(n_al):
+            r = ndt.align(guess)
+        ndt.synchronize()
+        el = allmax(time.perf_counter() - t0)
+        identical = True
+        if use_dist:
+            import torch
+            mine = torch.from_numpy(np.ascontiguousarray(r["T"]).view(np.int64).reshape(-1).copy())
+            allT = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allT, mine)
+            identical = all(bool(torch.equal(t, allT[0])) for t in allT)
+        ndt.comm_destroy()
+        out[kind] = {"ranks_seen": int(ranks_seen), "ms_per_align": 1e3 * el / n_al, "value": pts_all * a.iters * n_al / el,
+                     "unit": "source-points*iters/s", "iterations": int(r["iterations"]), "poses_identical_across_ranks": bool(identical),
+                     "final_pose_error_m": pose_error(r["T"], T_true)[0]}
+        if not identical:
+            raise SystemExit(f"sharded[{kind}]: ranks ended at different poses")
+    # the same shard without any collective attached (what the exchange costs on top)
+    for _ in range(2):
+        ndt.align(guess)
+    ndt.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ndt.align(guess)
+    ndt.synchronize()
+    out["no_collective_ms_per_align_this_shard"] = 1e3 * (time.perf_counter() - t0) / 10
+    return out, pts_rank, pts_all
+
+
+def replay_full_section(la, local, w, rp, a, rank, world, dist, use_dist):
+    """configs[4] as SURVEY.md §8(d) states it: 4096 pairs = 512 distinct configs[2]-sized scans x 8 hypotheses, the scans dealt
+    over the ranks in contiguous shares (independent units, no collective); each rank uploads its scans once and aligns all its
+    pairs in ONE batched call (ndt_align_batch_resident), repeated; whole-job time = max over ranks."""
+    from lio_slam_amd.shard import shard_range
+    from lio_slam_amd import synth
+    s_lo, s_hi = shard_range(REPLAY_SCANS, rank, world)
+    off = rp["offsets"]
+    scans = [np.asarray(rp["pts"][off[k]:off[k + 1]]) for k in range(s_lo, s_hi)]
+    n_sc = len(scans)
+    pair_scan = np.repeat(np.arange(n_sc, dtype=np.int32), REPLAY_HYP)
+    guesses = rp["guesses"][s_lo * REPLAY_HYP:s_hi * REPLAY_HYP]
+    truth = rp["T"][s_lo:s_hi]
+    nr = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+    nr.set_target(w["map"])
+    t0 = time.perf_counter(); nr.set_batch_sources(scans); up_ms = 1e3 * (time.perf_counter() - t0)
+    pts_rank = float(sum(len(scans[k]) for k in pair_scan))
+    r = nr.align_batch_resident(guesses, pair_scan)             # warm
+    nr.synchronize()
+    if use_dist:
+        dist.barrier()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = nr.align_batch_resident(guesses, pair_scan)
+    nr.synchronize()
+    el = time.perf_counter() - t0
+    if use_dist:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t[0])
+        t = torch.tensor([pts_rank, float(len(pair_scan))], dtype=torch.float64); dist.all_reduce(t); pts_all, pairs_all = float(t[0]), float(t[1])
+    else:
+        pts_all, pairs_all = pts_rank, float(len(pair_scan))
+    res = r.array
+    assert np.all(res["iterations"] == a.iters) and np.all(res["status"] == 0), "a replay pair did not run its fixed iterations"
+    errs = np.array([pose_error(r[p]["T"], truth[pair_scan[p]])[0] for p in range(len(pair_scan))])
+    stats = np.array([float(np.sum(errs < 0.05)), float(np.sum(res["last_dx_norm"] < 1e-2)), float(len(errs))])
+    if use_dist:
+        import torch
+        t = torch.from_numpy(stats); dist.all_reduce(t); stats = t.numpy()
+    gate = None
+    if rank == 0 and not a.no_cpu:
+        from oracle.oracle import Oracle
+        o = Oracle(nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+        o.set_threads(min(16, cpu_info()["cpus_usable"] or 1)); o.set_target(w["map"])
+        chk = sorted(set(int(x) for x in np.linspace(0, len(pair_scan) - 1, 8)))
+        worst = (0.0, 0.0)
+        for p in chk:
+            o.set_source(scans[pair_scan[p]])
+            dt, dr = pose_error(r[p]["T"], o.align(guesses[p])["T"])
+            worst = (max(worst[0], dt), max(worst[1], dr))
+        gate = {"pairs_checked": len(chk), "max_translation_m": worst[0], "max_rotation_rad": worst[1],
+                "passed": bool(worst[0] < POSE_TOL_M and worst[1] < POSE_TOL_RAD)}
+        if not gate["passed"]:
+            raise SystemExit(f"replay_full accuracy gate failed: {gate}")
+    nr.close()
+    return {"workload": "configs[4] in full: 4096 pairs = 512 distinct configs[2]-sized scans x 8 initial-pose hypotheses (up to 0.5 m / 5 deg) against the "
+                        "configs[2] map, scans dealt over the ranks, every rank's pairs in ONE batched align",
+            "pairs": int(pairs_all), "scans": REPLAY_SCANS, "hypotheses_per_scan": REPLAY_HYP, "pairs_this_rank": int(len(pair_scan)),
+            "source_bytes_this_rank": int(sum(len(x) for x in scans) * 12), "upload_ms_this_rank": up_ms,
+            "ms_per_job": 1e3 * el / reps, "pairs_per_s": pairs_all * reps / el, "value": pts_all * a.iters * reps / el,
+            "unit": "source-points*iters/s", "gn_iterations_per_pair": a.iters,
+            "share_within_5cm_of_truth": float(stats[0] / stats[2]), "share_last_step_below_1e-2": float(stats[1] / stats[2]),
+            "accuracy_gate": gate}
 
 
 def main():
@@ -318,8 +594,9 @@ def main():
     ap.add_argument("--mode", choices=["online", "sharded"], default="online")
     ap.add_argument("--comm", choices=["p2p", "rccl"], default="p2p", help="sharded mode's all-reduce: peer stores over xGMI (default) or RCCL")
     ap.add_argument("--small", action="store_true", help="200k-pt map (quick functional run, not a valid number)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the oracle accuracy gate")
-    ap.add_argument("--no-extras", action="store_true", help="skip the replay / large-map / PCL-mode sections")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the oracle accuracy gates")
+    ap.add_argument("--no-extras", action="store_true", help="skip the replay slice / large-map / PCL-mode sections")
+    ap.add_argument("--no-multi", action="store_true", help="skip the `sharded` and `replay_full` sections (the multi-GPU evidence)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "RANK" not in os.environ:       # decided before anything touches the GPU in this process
@@ -333,7 +610,7 @@ def main():
     devices_visible = None
     if use_dist:
         # rendezvous / barriers / timing reductions on CPU tensors (gloo); the data-path collective, where the
-        # mode has one, is RCCL inside libndt_mi355.so on the handle's own stream
+        # mode has one, is inside libndt_mi355.so on the handle's own stream
         import torch
         import torch.distributed as dist
         # gloo's C++ layer announces its connections on stdout; rank 0's stdout is for the ONE JSON line, so the
@@ -344,10 +621,14 @@ def main():
         devices_visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
         if devices_visible:
             local %= devices_visible                # fewer visible devices than ranks (a rehearsal on a one-GPU box): share them
+    dworld = world if use_dist else 1
+    multi = not a.no_multi and not a.small and a.mode == "online"
+    # host-side workloads that need worker processes are made before this process initialises the GPU
+    rp = prepare_replay_full(rank, dworld, dist) if multi else None
     import lio_slam_amd as la
     from lio_slam_amd import synth
 
-    w = load_workload(2, rank, world if use_dist else 1, dist, a.small)
+    w = load_workload(2, rank, dworld, dist, a.small)
     ndt = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
     counters = committed_counters()
 
@@ -368,15 +649,16 @@ def main():
         import torch
         t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t); return float(t[0])
 
-    t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
-    t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = min(build_ms, 1e3 * (time.perf_counter() - t0))
-    n_vox = ndt.num_voxels(); n_map = len(w["map"])
-    rb_ms, rb_passes = time_resident_build(ndt, w["map"])
-    build_rl = build_roofline(len(w["map"]), n_vox, rb_passes, rb_ms)
     extras = rank == 0 and world == 1 and not a.no_extras
     out = {}
+    nl = None                                   # the engine holding the 20M-point tiled map (sharded section, large_map section)
 
     if a.mode == "online":
+        t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter(); ndt.set_target(w["map"]); ndt.synchronize(); build_ms = min(build_ms, 1e3 * (time.perf_counter() - t0))
+        n_vox = ndt.num_voxels(); n_map = len(w["map"])
+        rb_ms, rb_passes = time_resident_build(ndt, w["map"])
+        build_rl = build_roofline(len(w["map"]), n_vox, rb_passes, rb_ms)
         # ---- the headline: a stream of LiDAR frames, one scan at a time, a keyframe merge every k-th frame
         scans = [w[f"scan{j}"] for j in range(8)]
         dev = [DeviceCloud(s) for s in scans]                                   # resident in HBM before the timed region
@@ -389,49 +671,53 @@ def main():
         g_ptr = [ctypes.c_void_p(x.ctypes.data) for x in g16]
         Tk_ptr = [ctypes.c_void_p(x.ctypes.data) for x in Tk16]
         d_ptr = [(d.ptr, ctypes.c_size_t(d.n), ctypes.c_size_t(12)) for d in dev]
-        n_frames = a.warmup + a.steps
         n_gate = 0 if a.no_cpu or rank != 0 else min(a.steps, max(12, a.keyframe_every + 2))
-        gate_T = []
-        merge_us, merges, pts_done = [], 0, 0.0
 
-        def frame(f, timed):
-            nonlocal merges, pts_done
-            j = (f + rank) % 8
-            # the frame is in HBM already and stays there: stream-ordered hand-over (the unpack runs on the engine's stream in front
-            # of the align's kernels, inside the timed region; there is no host wait in between)
-            rc = L.ndt_set_source_async(h, *d_ptr[j])
-            rc = rc or L.ndt_align(h, g_ptr[j], res_ref)
-            if rc:
-                raise la.NdtError(rc, L.ndt_last_error(h).decode())
-            if timed:
-                pts_done += dev[j].n
-                if res.iterations != a.iters:
-                    raise RuntimeError("an align did not run its fixed iterations")
-                if f - a.warmup < n_gate:
-                    gate_T.append(np.array(res.T).reshape(4, 4).T.copy())
-            if f % a.keyframe_every == a.keyframe_every - 1:                   # keyframe: the resident source joins the map
-                t1 = time.perf_counter()
-                rc = L.ndt_add_target_from_source(h, Tk_ptr[j])
+        def frame_stream(hand_over, n_warm, n_steps, keep_T=0):
+            """The frame loop: hand_over(f, j) makes scan j the source for frame f, then align from the frame's guess, then (every
+            k-th frame) the keyframe merge of the resident source.  Returns (seconds over the timed frames on this rank, points
+            aligned, merges, merge times, poses of the first keep_T timed frames)."""
+            merges, pts_done, merge_us, kept = 0, 0.0, [], []
+            t_start = None
+            for f in range(n_warm + n_steps):
+                if f == n_warm:
+                    barrier()
+                    t_start = time.perf_counter()
+                timed = f >= n_warm
+                j = (f + rank) % 8
+                rc = hand_over(f, j)
+                rc = rc or L.ndt_align(h, g_ptr[j], res_ref)
                 if rc:
                     raise la.NdtError(rc, L.ndt_last_error(h).decode())
                 if timed:
-                    merges += 1
-                    merge_us.append(1e6 * (time.perf_counter() - t1))
+                    pts_done += dev[j].n
+                    if res.iterations != a.iters:
+                        raise RuntimeError("an align did not run its fixed iterations")
+                    if f - n_warm < keep_T:
+                        kept.append(np.array(res.T).reshape(4, 4).T.copy())
+                if f % a.keyframe_every == a.keyframe_every - 1:                   # keyframe: the resident source joins the map
+                    t1 = time.perf_counter()
+                    rc = L.ndt_add_target_from_source(h, Tk_ptr[j])
+                    if rc:
+                        raise la.NdtError(rc, L.ndt_last_error(h).decode())
+                    if timed:
+                        merges += 1
+                        merge_us.append(1e6 * (time.perf_counter() - t1))
+            ndt.synchronize()
+            return time.perf_counter() - t_start, pts_done, merges, merge_us, kept
 
-        for f in range(a.warmup):
-            frame(f, False)
-        barrier()
-        t0 = time.perf_counter()
-        for f in range(a.warmup, n_frames):
-            frame(f, True)
-        ndt.synchronize()
-        el = allmax(time.perf_counter() - t0)
+        # the frame is in HBM already and stays there: stream-ordered hand-over (the records are read on the engine's stream by the
+        # align's first launch, inside the timed region; there is no host wait in between)
+        el_rank, pts_done, merges, merge_us, gate_T = frame_stream(lambda f, j: L.ndt_set_source_async(h, *d_ptr[j]), a.warmup, a.steps, n_gate)
+        el = allmax(el_rank)
         pts_all = allsum(pts_done)
         value = pts_all * a.iters / el
         n1 = dev[0].n
+        n_frames = a.warmup + a.steps
         last_T = np.array(res.T).reshape(4, 4).T.copy()
         jl = (n_frames - 1 + rank) % 8
         final_err = pose_error(last_T, w[f"T{jl}"])[0]
+        vox_end = int(ndt.num_voxels())
 
         # accuracy gate (outside the timed region): the oracle replays the same frames from the start — same map, same
         # merges at the same frames — and every gated align must land within 1e-4 m / 1e-5 rad of the oracle's pose
@@ -439,7 +725,7 @@ def main():
         if n_gate:
             from oracle.oracle import Oracle
             o = Oracle(nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
-            o.set_threads(min(16, os.cpu_count() or 1))
+            o.set_threads(min(16, cpu_info()["cpus_usable"] or 1))
             o.set_target(w["map"])
             worst = (0.0, 0.0)
             for f in range(a.warmup + n_gate):
@@ -456,6 +742,60 @@ def main():
                     "against": "oracle/ndt_oracle.c replaying the same frames and keyframe merges from the same map"}
             if not gate["passed"]:
                 raise SystemExit(f"accuracy gate failed: {gate}")
+
+        # ---- the drop-in path beside the resident one (what ndt_.setInputSource(pc_trans_filter), process.cc:87, costs a
+        # maintainer): the same frame loop with the scans coming from HOST memory.  Not `value` (§④: inputs resident).
+        from_host = None
+        if rank == 0 and world == 1:
+            hsteps, hwarm = max(20, min(a.steps, 100)), a.keyframe_every
+            host_np = [np.ascontiguousarray(s_, np.float32) for s_ in scans]                 # pageable
+            host_ptr = [(ctypes.c_void_p(x.ctypes.data), ctypes.c_size_t(len(x)), ctypes.c_size_t(12)) for x in host_np]
+            pinned = [PinnedFrame(s_) for s_ in scans]
+            pin_ptr = [(p_.ptr, ctypes.c_size_t(p_.n), ctypes.c_size_t(12)) for p_ in pinned]
+            hip = Hip.lib()
+            from_host = {"what": "the same online frame loop (align + keyframe merges) with every frame handed over from HOST memory: "
+                                 "blocking ndt_set_source of pageable / pinned records, and a double-buffered form — the caller copies frame "
+                                 "f+1 into one of two device buffers on its own stream (hipMemcpyAsync from pinned memory) while frame f "
+                                 "aligns, then hands the buffer over with ndt_set_source_async", "steps": hsteps}
+            for name, ptrs in (("pageable", host_ptr), ("pinned", pin_ptr)):
+                ndt.set_target(w["map"])
+                e_, p_, _, _, _ = frame_stream(lambda f, j, ptrs=ptrs: L.ndt_set_source(h, *ptrs[j]), hwarm, hsteps)
+                from_host[name] = {"value": p_ * a.iters / e_, "ms_per_step": 1e3 * e_ / hsteps}
+            # double-buffered: two device buffers of the caller, a copy stream, one event per buffer
+            cap = max(d.n for d in dev) * 12
+            dbuf = [ctypes.c_void_p(), ctypes.c_void_p()]
+            evs = [ctypes.c_void_p(), ctypes.c_void_p()]
+            cstream = ctypes.c_void_p()
+            for b_ in range(2):
+                Hip.check(hip.hipMalloc(ctypes.byref(dbuf[b_]), ctypes.c_size_t(cap)), "hipMalloc")
+                Hip.check(hip.hipEventCreateWithFlags(ctypes.byref(evs[b_]), 2), "hipEventCreateWithFlags")     # hipEventDisableTiming
+            Hip.check(hip.hipStreamCreateWithFlags(ctypes.byref(cstream), 1), "hipStreamCreateWithFlags")       # hipStreamNonBlocking
+
+            def copy_in(f):
+                j = (f + rank) % 8
+                b_ = f & 1
+                Hip.check(hip.hipMemcpyAsync(dbuf[b_], pinned[j].ptr, ctypes.c_size_t(pinned[j].nbytes), 1, cstream), "hipMemcpyAsync")
+                Hip.check(hip.hipEventRecord(evs[b_], cstream), "hipEventRecord")
+
+            def hand_over_db(f, j):
+                if f == 0:
+                    copy_in(0)
+                copy_in(f + 1)                                                          # next frame's copy runs under this frame's align
+                Hip.check(hip.hipEventSynchronize(evs[f & 1]), "hipEventSynchronize")       # this frame's copy was queued a frame ago
+                return L.ndt_set_source_async(h, dbuf[f & 1], ctypes.c_size_t(pinned[j].n), ctypes.c_size_t(12))
+
+            ndt.set_target(w["map"])
+            e_, p_, _, _, _ = frame_stream(hand_over_db, hwarm, hsteps)
+            Hip.check(hip.hipStreamSynchronize(cstream), "hipStreamSynchronize")
+            from_host["pinned_double_buffered"] = {"value": p_ * a.iters / e_, "ms_per_step": 1e3 * e_ / hsteps,
+                                                   "over_resident_value": (p_ * a.iters / e_) / value}
+            ndt.set_source(dev[0].view())                                               # nothing pending on the caller's buffers any more
+            for b_ in range(2):
+                hip.hipFree(dbuf[b_]); hip.hipEventDestroy(evs[b_])
+            hip.hipStreamDestroy(cstream)
+            for p_ in pinned:
+                p_.free()
+            ndt.set_target(w["map"])
 
         # roofline of the dominant kernel (the chained residual + step launch, one per iteration): HIP events on the
         # engine's stream around back-to-back launches of that kernel alone, right after the timed region
@@ -474,104 +814,65 @@ def main():
                                     f"GPU-resident voxel map of a 2M-pt keyframe map, keyframe merge every {a.keyframe_every} frames"
                                     + (" (SMALL 200k-pt map: not a valid number)" if a.small else "")),
                        "mode": "online", "frames_per_step_per_gpu": 1, "source_points_per_step_per_gpu": int(n1), "map_points": int(n_map),
-                       "voxels_at_start": int(n_vox), "voxels_at_end": int(ndt.num_voxels()), "nearby": a.nearby, "resolution_m": 1.0,
+                       "voxels_at_start": int(n_vox), "voxels_at_end": vox_end, "nearby": a.nearby, "resolution_m": 1.0,
                        "gn_iterations_per_align": a.iters, "keyframe_every": a.keyframe_every,
                        "parallelism": f"frames{world}" if world > 1 else "1gpu",
-                       "multi_gpu": "each rank replays its own frame stream against its own map replica; no data-path collective"},
+                       "multi_gpu": "value: each rank replays its own frame stream against its own map replica, no data-path collective; "
+                                    "the sharded-source and full-replay jobs run in the same command: `sharded`, `replay_full`"},
             "scans_per_s": a.steps * world / el, "keyframe_merges_timed": merges,
             "keyframe_merge_ms": (float(np.mean(merge_us)) / 1e3) if merge_us else None,
             "map_build_ms": build_ms, "map_build_roofline": build_rl,
             "roofline": rl, "accuracy_gate": gate, "final_pose_error_m": final_err,
+            "online_from_host": from_host,
         }
         for d in dev[1:]:
             d.free()
+        if multi:
+            # ---- the multi-GPU evidence, in the driver's one command (also at N = 1, so that the curves have an origin)
+            lm = large_map_workload(rank, dworld, dist)
+            nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+            nl.set_target(lm["map"]); nl.synchronize()
+            sh, _, _ = sharded_section(la, nl, lm["scan"], lm["guess"], lm["T_true"], a, rank, world, dist, use_dist, ("p2p", "rccl"))
+            sh["voxels"] = int(nl.num_voxels()); sh["map_points"] = int(len(lm["map"])); sh["n_gpus"] = world
+            out["sharded"] = sh
+            if not extras:
+                nl.close(); nl = None
+            rf = replay_full_section(la, local, w, rp, a, rank, world, dist, use_dist)
+            rf["n_gpus"] = world
+            out["replay_full"] = rf
     else:
-        # ---- configs[3]: ONE dense scan (128 rings x 15 625 azimuth steps, ~2 M returns, taken at the same pose in the same
-        # yard) against a 20 M-point map of that yard; the source is cut into contiguous ranges, one per rank
-        from lio_slam_amd.shard import shard_range
-        guess, T = w["guess"], w["T_true"]
-        big_map, scan_all = load_dense_workload(w, rank, world if use_dist else 1, dist)
-        ndt.set_target(big_map); ndt.synchronize()
-        t0 = time.perf_counter(); ndt.set_target(big_map); ndt.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
-        n_vox = ndt.num_voxels(); n_map = len(big_map)
-        rb_ms, rb_passes = time_resident_build(ndt, big_map)
-        build_rl = build_roofline(n_map, n_vox, rb_passes, rb_ms); del big_map
-        lo, hi = shard_range(len(scan_all), rank, world)
-        ranks_seen = 1
-        comm_kind = None
-        ndt.set_source(scan_all[lo:hi])                      # resident in HBM before the timed region
-        if use_dist:
-            import torch
-            if a.comm == "p2p":
-                # peer exchange: every rank's mailbox handle to every rank (gloo), peers opened over HIP IPC, then one align
-                # as a probe (its waits are bounded: a peer whose stores do not arrive ends it with NDT_ERR_COMM on every
-                # rank); all ranks fall back to RCCL together if any of them could not open a peer or finish the probe
-                handles = [None] * world
-                try:
-                    mine = ndt.comm_p2p_export()
-                except la.NdtError as e:
-                    print(f"[bench] rank {rank}: no mailbox to export ({e})", file=sys.stderr); mine = None
-                dist.all_gather_object(handles, mine)
-                try:
-                    if any(hd is None for hd in handles):
-                        raise la.NdtError(-1, "a rank exported no mailbox")
-                    ndt.comm_p2p_init(rank, world, handles); ndt.align(guess); ok = 1
-                except la.NdtError as e:
-                    print(f"[bench] rank {rank}: peer exchange unavailable ({e}); RCCL instead", file=sys.stderr); ok = 0
-                t_ok = torch.tensor([ok]); dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-                if int(t_ok.item()) == 1:
-                    comm_kind = "p2p"
-                else:
-                    ndt.comm_destroy()
-            if comm_kind is None:
-                with stdout_to_stderr():                         # RCCL prints its version banner on stdout
-                    ids = [la.NDT.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(ids, src=0)
-                    ndt.comm_init(rank, world, ids[0])
-                comm_kind = "rccl"
-            ranks_seen = ndt.comm_size()
-        pts_rank = float(ndt.source_size())
-        for _ in range(a.warmup):
-            r = ndt.align(guess)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            r = ndt.align(guess)
-        ndt.synchronize()
-        el = allmax(time.perf_counter() - t0)
-        assert r["iterations"] == a.iters, "an align did not run its fixed iterations"
-        pts_all = allsum(pts_rank)
-        value = pts_all * a.iters * a.steps / el
-        identical = True
-        if use_dist:                                           # every rank took the same all-reduced steps: identical poses, bit for bit
-            import torch
-            mine = torch.from_numpy(np.ascontiguousarray(r["T"]).view(np.int64).reshape(-1).copy())
-            allT = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allT, mine)
-            identical = all(bool(torch.equal(t, allT[0])) for t in allT)
-            assert identical, "ranks ended at different poses"
-        k_us = 0.5 * (ndt.time_residual(guess, 300) + ndt.time_residual(r["T"], 300))
-        ndt.profile(True); ndt.eval(guess); ndt.eval(r["T"]); h1 = ndt.profile_read()["hits_per_point"]; ndt.profile(False)
-        kname = f"k_residual<{a.nearby}>"
+        # ---- --mode sharded: configs[3] as the headline of the line (value = the chosen collective's rate)
+        lm = large_map_workload(rank, dworld, dist)
+        nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+        nl.set_target(lm["map"]); nl.synchronize()
+        t0 = time.perf_counter(); nl.set_target(lm["map"]); nl.synchronize(); build_ms = 1e3 * (time.perf_counter() - t0)
+        n_vox = nl.num_voxels(); n_map = len(lm["map"])
+        rb_ms, rb_passes = time_resident_build(nl, lm["map"], reps=2)
+        build_rl = build_roofline(n_map, n_vox, rb_passes, rb_ms)
+        other = "rccl" if a.comm == "p2p" else "p2p"
+        sh, pts_rank, pts_all = sharded_section(la, nl, lm["scan"], lm["guess"], lm["T_true"], a, rank, world, dist, use_dist, (a.comm, other))
+        kind = a.comm if "error" not in sh[a.comm] else other
+        if "error" in sh[kind]:
+            raise SystemExit(f"sharded mode: no collective could attach: {sh}")
+        best = sh[kind]
+        k_us = 0.5 * (nl.time_residual(lm["guess"], 100) + nl.time_residual(lm["T_true"], 100))
+        nl.profile(True); nl.eval(lm["guess"]); nl.eval(lm["T_true"]); h1 = nl.profile_read()["hits_per_point"]; nl.profile(False)
         out = {
-            "metric": "NDT source-points*iters/sec (2M-pt source vs 20M-pt map, source sharded over the GPUs)", "value": value,
-            "unit": "source-points*iters/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "metric": "NDT source-points*iters/sec (2M-pt source vs 20M-pt map, source sharded over the GPUs)", "value": best["value"],
+            "unit": "source-points*iters/s", "n_gpus": world, "ranks_seen": best["ranks_seen"], "steps": 10, "warmup": 3,
+            "ms_per_step": best["ms_per_align"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[3]: ONE dense ~2M-point scan sharded over the ranks against the GPU-resident voxel map of a "
-                                   "20M-point map (replicated per rank), all-reduce of H,b per iteration "
-                                   "(p2p: peer stores into the ranks' mailboxes over xGMI; rccl: ncclAllReduce)",
-                       "mode": "sharded", "collective": comm_kind, "source_points_per_step_per_gpu": int(pts_rank), "source_points_total": int(pts_all),
-                       "map_points": int(n_map), "voxels": int(n_vox), "nearby": a.nearby, "resolution_m": 1.0,
-                       "gn_iterations_per_align": a.iters, "parallelism": f"sharded{world}"},
-            "scans_per_s": a.steps / el, "poses_identical_across_ranks": identical,
-            "map_build_ms": build_ms, "map_build_roofline": build_rl,
-            "roofline": residual_roofline(kname, pts_rank, a.nearby, h1, k_us, counters),
-            "final_pose_error_m": pose_error(r["T"], T)[0],
+            "config": {"workload": sh["workload"], "mode": "sharded", "collective": kind, "source_points_per_step_per_gpu": int(pts_rank),
+                       "source_points_total": int(pts_all), "map_points": int(n_map), "voxels": int(n_vox), "nearby": a.nearby,
+                       "resolution_m": 1.0, "gn_iterations_per_align": a.iters, "parallelism": f"sharded{world}"},
+            "scans_per_s": 1e3 / best["ms_per_align"], "poses_identical_across_ranks": best["poses_identical_across_ranks"],
+            "sharded": sh, "map_build_ms": build_ms, "map_build_roofline": build_rl,
+            "roofline": gather_bound(residual_roofline(f"k_residual<{a.nearby}>", pts_rank, a.nearby, h1, k_us, counters, f"k_residual<{a.nearby}>@large_map")),
+            "final_pose_error_m": best["final_pose_error_m"],
         }
+        nl.close(); nl = None
     if devices_visible is not None:
         out["devices_visible"] = devices_visible
-
     if extras and a.mode == "online":
         # ---- replay: configs[4]-style offline replay of configs[2]-sized pairs, `batch` independent (scan, initial pose)
         # pairs per step, all scans resident in HBM
@@ -604,7 +905,7 @@ def main():
         if not a.no_cpu:
             from oracle.oracle import Oracle
             o = Oracle(nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
-            o.set_threads(min(16, os.cpu_count() or 1)); o.set_target(w["map"])
+            o.set_threads(min(16, cpu_info()["cpus_usable"] or 1)); o.set_target(w["map"])
             worst = (0.0, 0.0)
             chk = sorted(set([0, 1, a.batch // 2, a.batch - 1]))
             for p in chk:
@@ -622,9 +923,11 @@ def main():
                          "roofline": residual_roofline(f"k_residual_batch<{a.nearby}>", ppl, a.nearby, hb, kb_us, counters)}
         nr.close()
 
-        # ---- large map: the regime the HBM roofline is about (table beyond every L2)
+        # ---- large map: the regime the HBM roofline is about (table beyond every L2); the engine of the sharded section,
+        # with the whole 2M-point source
         lm = large_map_workload()
-        nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
+        if nl is None:
+            nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
         t0 = time.perf_counter(); nl.set_target(lm["map"]); nl.synchronize(); lb_ms = 1e3 * (time.perf_counter() - t0)
         lrb_ms, lrb_p = time_resident_build(nl, lm["map"], reps=2)
         nl.set_source(lm["scan"])
@@ -646,8 +949,8 @@ def main():
                             "source_points": int(nsrc), "map_points": int(len(lm["map"])), "voxels": int(nl.num_voxels()),
                             "final_pose_error_m": pose_error(rl_["T"], lm["T_true"])[0],
                             "map_build_ms": lb_ms, "map_build_roofline": build_roofline(len(lm["map"]), nl.num_voxels(), lrb_p, lrb_ms),
-                            "roofline": residual_roofline(f"k_residual<{a.nearby}>", nsrc, a.nearby, hl, kl_us, counters, f"k_residual<{a.nearby}>@large_map")}
-        nl.close()
+                            "roofline": gather_bound(residual_roofline(f"k_residual<{a.nearby}>", nsrc, a.nearby, hl, kl_us, counters, f"k_residual<{a.nearby}>@large_map"))}
+        nl.close(); nl = None
 
         # ---- large dense map: the configs[2] voxel map itself (same voxels, same hits per point as the headline) on a
         # 10 x 10 grid of tiles 300 cells apart, loaded through ndt_map_load: 2.2 M voxels, keys + slots touched ~600 MB —
@@ -688,7 +991,7 @@ def main():
                                   "source_points": int(nsd), "voxels": int(nd.num_voxels()), "map_load_ms": ld_ms,
                                   "keyframe_merge_ms": float(np.median(mt)), "keyframe_points": int(len(w["scan0"])),
                                   "final_pose_error_m": pose_error(rd["T"], T0)[0],
-                                  "roofline": residual_roofline(f"k_residual<{a.nearby}>", nsd, a.nearby, hd, kd_us, counters, f"k_residual<{a.nearby}>@large_dense")}
+                                  "roofline": gather_bound(residual_roofline(f"k_residual<{a.nearby}>", nsd, a.nearby, hd, kd_us, counters, f"k_residual<{a.nearby}>@large_dense"))}
         nd.close()
 
         # ---- PCL compatibility mode: the objective / optimiser the reference's PCL build runs, on the

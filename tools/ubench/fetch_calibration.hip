@@ -85,13 +85,31 @@ __global__ __launch_bounds__(256) void k_cal_pattern_coh(const Slot* __restrict_
     }
     if (acc == 123.456f) out[0] = acc;
 }
+// timing mode: M distinct random 64-byte slots per lane, all 4 M loads issued before any is used
+template <int M>
+__global__ __launch_bounds__(256) void k_cal_mlp(const Slot* __restrict__ t, const uint32_t* __restrict__ idx, size_t n, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (i < n) {
+        uint32_t s[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) s[k] = idx[(size_t)k * n + i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) acc += use64(t + s[k]);
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
 __global__ void k_cal_fill(int4* p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_int4((int)i, 1, 2, 3);
 }
 
 int main(int argc, char** argv) {
-    const size_t n_slots = (size_t)1 << 25;                 // 32 Mi slots x 64 B = 2 GiB: far beyond L2 (32 MB) and the 256 MB Infinity Cache
-    const size_t n_lanes = (size_t)1 << 22;                 // 4 Mi lanes per gather kernel: 7 x 4 Mi = 28 Mi distinct slots < n_slots
+    // default: 32 Mi slots x 64 B = 2 GiB, far beyond L2 (32 MB) and the 256 MB Infinity Cache; 4 Mi lanes per gather kernel
+    // (7 x 4 Mi = 28 Mi distinct slots < n_slots).  `time <log2 slots>`: another table size (lanes = slots / 8)
+    const int lg = argc > 2 ? atoi(argv[2]) : 25;
+    if (lg < 16 || lg > 27) { fprintf(stderr, "log2 slots must be 16..27\n"); return 1; }
+    const size_t n_slots = (size_t)1 << lg;
+    const size_t n_lanes = n_slots >> 3;
     Slot* table = nullptr; uint32_t* idx = nullptr; float* out = nullptr;
     CHECK(hipMalloc(&table, n_slots * sizeof(Slot)));
     CHECK(hipMalloc(&idx, 7 * n_lanes * 4));
@@ -105,6 +123,29 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < 7 * n_lanes; ++i) { std::uniform_int_distribution<size_t> d(i, n_slots - 1); std::swap(perm[i], perm[d(rng)]); }
     CHECK(hipMemcpy(idx, perm.data(), 7 * n_lanes * 4, hipMemcpyHostToDevice));
     const unsigned nb = (unsigned)(n_lanes / 256);
+    if (argc > 1 && argv[1][0] == 't') {
+        // `fetch_calibration time`: the random-64-byte-line gather rate of this GPU by loads in flight per lane (HIP events, no
+        // profiler; the 0.27 - 1.9 GB a kernel touches are far beyond the 256 MB Infinity Cache, so repeats stay uncached)
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        auto timeit = [&](const char* name, int m, auto&& launch) {
+            launch(); CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int r = 0; r < 5; ++r) launch();
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms = 0.f; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / 5.0, bytes = (double)n_lanes * m * 64.0;
+            printf("%-34s %8.1f us  %6.2f TB/s of 64-byte lines (%.0f MB per launch)\n", name, us, bytes / us / 1e6, bytes / 1e6);
+        };
+        printf("table %zu MB\n", n_slots * 64 >> 20);
+        timeit("stream 16 B/lane (whole table)", 8, [&] { k_cal_stream16<<<8192, 256>>>((const int4*)table, n_slots * 4, out); });
+        timeit("random slot, 1 in flight per lane", 1, [&] { k_cal_mlp<1><<<nb, 256>>>(table, idx, n_lanes, out); });
+        timeit("random slot, 2 in flight per lane", 2, [&] { k_cal_mlp<2><<<nb, 256>>>(table, idx, n_lanes, out); });
+        timeit("random slot, 4 in flight per lane", 4, [&] { k_cal_mlp<4><<<nb, 256>>>(table, idx, n_lanes, out); });
+        timeit("random slot, 7 in flight per lane", 7, [&] { k_cal_mlp<7><<<nb, 256>>>(table, idx, n_lanes, out); });
+        timeit("engine pattern (64 + 6 x 40 B)", 7, [&] { k_cal_pattern<<<nb, 256>>>(table, idx, n_lanes, out); });
+        return 0;
+    }
     // a 2 GiB stream between the kernels evicts whatever the previous one left in the caches
     auto flush = [&]() { k_cal_fill<<<4096, 256>>>((int4*)table, n_slots * 4); };
     flush(); k_cal_stream16<<<8192, 256>>>((const int4*)table, n_slots * 4, out);
