@@ -143,3 +143,29 @@ def test_public_headers_compile_standalone(tmp_path):
         cc.write_text(f'#include "{hdr}"\nint main() {{ return 0; }}\n')
         out = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cc)], capture_output=True, text=True)
         assert out.returncode == 0, hdr + "\n" + out.stderr
+
+
+def test_replay_set_is_dealt_completely_and_reproducibly():
+    """bench.py's configs[4] job (512 scans x 8 hypotheses) is dealt over the ranks in contiguous scan shares: for every
+    world size the driver uses, every scan — and so every one of the 4096 pairs — lands on exactly one rank, shares differ by
+    at most one scan, and a scan's generator depends on its index only (so any rank could regenerate any scan)."""
+    import bench
+    from lio_slam_amd.shard import shard_range
+    for world in (1, 2, 3, 4, 8, 16):
+        spans = [shard_range(bench.REPLAY_SCANS, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == bench.REPLAY_SCANS
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+        assert sum(sizes) * bench.REPLAY_HYP == 4096
+    s0, T0, g0 = bench._replay_scan_job(3)
+    s1, T1, g1 = bench._replay_scan_job(3)
+    s2, T2, _ = bench._replay_scan_job(4)
+    assert np.array_equal(s0, s1) and np.array_equal(T0, T1) and np.array_equal(g0, g1)
+    assert s0.dtype == np.float32 and s0.shape[1] == 3 and 100_000 < len(s0) < 120_001 and g0.shape == (bench.REPLAY_HYP, 4, 4)
+    assert not np.array_equal(T0, T2) and len(s2) != len(s0) or not np.array_equal(s0[:100], s2[:100])
+    # hypotheses stay within 0.5 m / 5 degrees of the scan's pose
+    for g in g0:
+        d = np.linalg.inv(T0) @ g
+        assert np.linalg.norm(d[:3, 3]) <= 0.5 + 1e-9
+        assert np.degrees(np.arccos(min(1.0, (np.trace(d[:3, :3]) - 1) / 2))) <= 5.0 + 1e-6
