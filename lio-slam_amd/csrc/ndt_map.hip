@@ -2085,7 +2085,7 @@ int map_restore(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, const int64_t* 
 //   k_evict          voxels at or below that stamp become empty cells again: key and neighbour links stay (the cell is what
 //                    a ghost cell is — DESIGN.md §3 — so no link anywhere has to change), points, statistics and payload go.
 // Evicted cells stay in the table as ghost cells; when those outnumber the voxels eight to one the table is rebuilt from
-// the voxels alone (map_compact: the dump / restore pair of the serialised maps, stamps included).
+// the voxels alone, on the device (map_compact: k_compact_move + the ghost stage; stamps carried).
 
 __global__ __launch_bounds__(256) void k_touch_points(const unsigned char* raw, const float* soa_y, const float* soa_z, size_t n, size_t stride, int has_T, RtArg rt,
                                                       KeyParams kp, const int64_t* keys, uint64_t mask, unsigned long long* touch, unsigned long long stamp0) {
@@ -2149,15 +2149,61 @@ __global__ __launch_bounds__(256) void k_evict(VoxSlot* slots, int32_t* counts, 
     }
 }
 
+// The table rebuilt from its voxels alone, ON THE DEVICE (no host round trip of the map, no host sort, no allocation beyond
+// the new table itself): every entry that holds points moves into a fresh table — key, payload, count, statistics, LRU stamp
+// — and leaves its key in a list; the ghost stage then makes the neighbours and links of that list as it does for the new
+// voxels of any batch.  Runs inside a keyframe merge when dropped cells outnumber the voxels eight to one.
+__global__ void k_compact_move(const int64_t* ok, const VoxSlot* os, const int32_t* on, const double* om, const double* oc, const unsigned long long* ot,
+                               size_t ocap, VoxSlot* ns, int64_t* nk, int32_t* nn, double* nm, double* nc, unsigned long long* nt, uint64_t nmask,
+                               int64_t* list, uint32_t* n_list) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ocap) return;
+    const int64_t key = ok[i];
+    if (key == NDT_KEY_EMPTY || on[i] <= 0) return;       // empty, a ghost cell, or a dropped voxel
+    uint64_t slot = ndt_hash_key(key) & nmask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&nk[slot], (unsigned long long)NDT_KEY_EMPTY, (unsigned long long)key);
+        if ((int64_t)prev == NDT_KEY_EMPTY) break;
+        slot = (slot + 1) & nmask;
+    }
+    if (slot < 4) nk[nmask + 1 + slot] = key;
+    VoxSlot v = os[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v.link[j] = NDT_LINK_NONE;      // the ghost stage links the new table
+    ns[slot] = v;
+    nn[slot] = on[i];
+    for (int j = 0; j < 3; ++j) nm[slot * 3 + j] = om[i * 3 + j];
+    for (int j = 0; j < 6; ++j) nc[slot * 6 + j] = oc[i * 6 + j];
+    if (ot) nt[slot] = ot[i];
+    list[atomicAdd(n_list, 1u)] = key;
+}
 static int map_compact(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, hipStream_t s, std::string& err) {
-    std::vector<int64_t> k; std::vector<int32_t> c; std::vector<double> mu, cv; std::vector<unsigned long long> st;
-    int rc = map_dump(m, k, c, mu, cv, s, err, &st);
-    if (rc != NDT_OK) return rc;
-    if (getenv("NDT_DEBUG_LRU")) fprintf(stderr, "[ndt] table rebuilt from %zu voxels (%lld entries before)\n", k.size(), (long long)m.n_entries);
-    const uint32_t cloud_no = m.cloud_no;
-    HIP_TRY(map_clear(m, s));
-    m.cloud_no = cloud_no;
-    return map_restore(m, w, cfg, k.data(), c.data(), mu.data(), cv.data(), k.size(), s, err, st.data());
+    (void)cfg;
+    const size_t nv = (size_t)m.n_vox;
+    if (getenv("NDT_DEBUG_LRU")) fprintf(stderr, "[ndt] table rebuilt on the device from %zu voxels (%lld entries before)\n", nv, (long long)m.n_entries);
+    VoxelMap nm;
+    nm.track_touch = m.track_touch; nm.cloud_no = m.cloud_no;
+    HIP_TRY(map_alloc(nm, pow2_at_least(std::max<size_t>(nv, 1) * 5), s));      // voxels + their ghost cells at the usual ratio, load <= 1/2
+    HIP_TRY(w.misc.ensure(256));
+    HIP_TRY(w.keys_a.ensure(std::max<size_t>(nv, 1) * 8));
+    int32_t* plan = w.misc.as<int32_t>();
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 160, 0, 32, s));
+    HIP_TRY(hipMemsetAsync((char*)w.misc.p + 4 * PL_NSEG, 0, 28, s));       // nseg .. sort error
+    k_compact_move<<<(unsigned)((m.cap + 255) / 256), 256, 0, s>>>(m.keys, m.slots, m.counts, m.mean, m.cov, m.touch, m.cap, nm.slots, nm.keys, nm.counts, nm.mean,
+                                                                  nm.cov, nm.touch, (uint64_t)(nm.cap - 1), w.keys_a.as<int64_t>(), (uint32_t*)(plan + PL_NSEG));
+    // the host's voxel count is exact, so the list's length is known without a read-back
+    k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_VOX, (int32_t)nv);
+    k_set_word<<<1, 1, 0, s>>>(plan + PL_NEW_ENT, (int32_t)nv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));        // the old table is read until here
+    map_free(m);
+    m = nm;                                  // n_vox = n_entries = 0: the ghost stage adds the plan's counts
+    SegKeys K{};
+    K.plain = w.keys_a.as<int64_t>(); K.d_count = plan + PL_NSEG;
+    PlanWords pw;
+    int rc = ghost_stage(m, w, K, (uint32_t)nv, PL_NEW_VOX, PL_NEW_ENT, &pw, s, err);
+    if (rc == NDT_OK && (size_t)pw.nseg != nv) { err = "table rebuild: the device moved " + std::to_string(pw.nseg) + " voxels, the host counted " + std::to_string(nv); return NDT_ERR_HIP; }
+    return rc;
 }
 
 int map_lru_step(VoxelMap& m, MapWork& w, const MapBuildCfg& cfg, hipStream_t s, std::string& err) {

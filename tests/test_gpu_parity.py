@@ -178,12 +178,13 @@ def _moving_clouds(seed, n_clouds, pts_per_cloud, step):
     return [(r.uniform([0, 0, 0], [12, 6, 2], (pts_per_cloud, 3)) + [step * c, 0, 0]).astype(np.float32) for c in range(n_clouds)]
 
 
-def test_lru_capacity_parity(mods):
+def test_lru_capacity_parity(mods, monkeypatch, capfd):
     """`capacity` (IncNdt3d's LRU voxel list): after every merge the engine holds the same capacity - 1
     voxels with the same statistics as the oracle (whose eviction order is pinned against a point-by-point model of the list
     in test_oracle_golden.py), evaluates a scan the same, and goes on merging into cells it had dropped.  The last case moves
     a whole box per cloud for 130 clouds, so the dropped cells pile up and the table is rebuilt from the voxels on the way."""
     la, synth, Oracle = mods
+    monkeypatch.setenv("NDT_DEBUG_LRU", "1")                 # the engine reports a table rebuild on stderr
     for capacity, step, n_clouds in ((120, 3.0, 9), (60, 5.0, 9), (200, 1.0, 9), (300, 12.0, 130)):
         clouds = _moving_clouds(11 + capacity, n_clouds, 1500, step)
         opts = dict(min_pts_in_voxel=3, capacity=capacity)
@@ -203,6 +204,9 @@ def test_lru_capacity_parity(mods):
         o.set_source(src); n.set_source(src)
         _cmp_eval(n.eval(np.eye(4)), o.eval(np.eye(4)))
         n.close()
+    # the 130-cloud case rebuilt its table mid-stream, on the device (k_compact_move + ghost stage), and every map after it
+    # still matched the oracle above
+    assert "table rebuilt on the device" in capfd.readouterr().err
     with pytest.raises(la.NdtError):
         la.NDT(capacity=1)
 
