@@ -340,9 +340,13 @@ def gather_bound(rl):
     line bytes at 256 MB - 2 GB tables, whatever the loads in flight), not the 8 TB/s of a stream."""
     if rl.get("traffic") is not None:
         gbs = rl["traffic"] / (rl["kernel_avg_us"] * 1e-6) / 1e9
-        rl["random_line_gather_GBps_measured_ceiling"] = GATHER64_GBS
+        rl["frac_of_streaming_peak"] = gbs / HBM_PEAK_GBS
         rl["frac_of_random_line_gather_rate"] = gbs / GATHER64_GBS
-        rl["regime"] = "random 64-byte-line fetches from HBM (table beyond L2 and Infinity Cache)"
+        rl.update({"bound": "hbm (random 64-byte lines)", "achieved": gbs, "peak": GATHER64_GBS, "unit": "GB/s", "frac": gbs / GATHER64_GBS,
+                   "peak_source": "measured on this GPU: tools/ubench/fetch_calibration time -> profiles/r03_gather_rate.txt (3.1-3.25 TB/s of line bytes; a stream reaches 6.4-7.1, the spec peak is 8)",
+                   "how": "MEASURED HBM line bytes per launch (FETCH_SIZE at the calibrated factor 1.0 + WRITE_SIZE) / live kernel time / the random-line gather rate; "
+                          "against the 8 TB/s streaming peak the same bytes are `frac_of_streaming_peak`",
+                   "regime": "random 64-byte-line fetches from HBM (table beyond L2 and Infinity Cache)"})
     return rl
 
 

@@ -92,3 +92,42 @@ def test_align_static_matches_align_on_two_calls_in_a_row():
     finally:
         big_d.free(); small_d.free()
     n.close()
+
+
+def test_align_static_from_two_host_threads_takes_turns():
+    """Every handle on a GPU shares that GPU's scratch array; the library serialises ndt_align_static calls per device, so two
+    host threads calling it on two handles at once get exactly what they get one after the other (before round 3 they raced
+    on the rows and states and returned wrong poses with rc 0)."""
+    import threading
+    import lio_slam_amd as la
+    from lio_slam_amd import synth
+    hip = ctypes.CDLL("libamdhip64.so")
+    c = synth.make_config(1, small=True)
+    clouds = [c["scan"], np.ascontiguousarray(c["scan"][::2])]
+    handles = [la.NDT(max_iterations=12, eps=0.0), la.NDT(max_iterations=9, eps=0.0, nearby=1)]
+    dev = [DeviceSoA(hip, s) for s in clouds]
+    try:
+        for h in handles:
+            h.set_target(c["map"])
+        serial = [[handles[i].align_static(dev[i].ptr[0].value, dev[i].ptr[1].value, dev[i].ptr[2].value, dev[i].n, c["guess"]) for _ in range(3)]
+                  for i in range(2)]
+        out = [[], []]
+
+        def work(i):
+            for _ in range(40):
+                out[i].append(handles[i].align_static(dev[i].ptr[0].value, dev[i].ptr[1].value, dev[i].ptr[2].value, dev[i].n, c["guess"]))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for i in range(2):
+            assert len(out[i]) == 40
+            for r in out[i]:
+                _same(r, serial[i][0])
+    finally:
+        for d in dev:
+            d.free()
+        for h in handles:
+            h.close()
