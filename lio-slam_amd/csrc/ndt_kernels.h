@@ -37,6 +37,33 @@ __device__ __forceinline__ double swap_add16(double a, double b) {   // even 16-
     const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
+// value of lane (lane ^ BIT), BIT = 8, 4, 2 or 1, through DPP moves inside a row of 16 lanes (no LDS crossbar round trip, which
+// ds_bpermute — what __shfl_xor compiles to — costs: four dependent ones on the critical tail of every residual launch).
+// BIT = 8 / 4: lanes whose bit is set take the value BIT lanes below them (row_shr), the others BIT lanes above (row_shl);
+// the bank mask selects which four-lane banks of each row a move writes.  BIT = 2 / 1: one quad permutation.
+template <int BIT>
+__device__ __forceinline__ int xor_lane_dpp(int v) {
+    if constexpr (BIT == 8) {
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x118 /* row_shr:8 */, 0xf, 0xc, false);
+        return __builtin_amdgcn_update_dpp(t, v, 0x108 /* row_shl:8 */, 0xf, 0x3, false);
+    } else if constexpr (BIT == 4) {
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+        return __builtin_amdgcn_update_dpp(t, v, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    } else if constexpr (BIT == 2) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+    } else {
+        static_assert(BIT == 1, "xor_lane_dpp: BIT must be 8, 4, 2 or 1");
+        return __builtin_amdgcn_update_dpp(v, v, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+    }
+}
+template <int BIT>
+__device__ __forceinline__ double xor_lane(double x) {
+#ifdef NDT_NO_DPP_BUTTERFLY
+    return __shfl_xor(x, BIT);
+#else
+    return __hiloint2double(xor_lane_dpp<BIT>(__double2hiint(x)), xor_lane_dpp<BIT>(__double2loint(x)));
+#endif
+}
 template <int HALF, int BIT>
 __device__ __forceinline__ void rs_step(double* acc, int lane) {
     const bool up = (lane & BIT) != 0;
@@ -44,7 +71,7 @@ __device__ __forceinline__ void rs_step(double* acc, int lane) {
     for (int j = 0; j < HALF; ++j) {
         const double send = up ? acc[j] : acc[j + HALF];
         const double keep = up ? acc[j + HALF] : acc[j];
-        acc[j] = keep + __shfl_xor(send, BIT);
+        acc[j] = keep + xor_lane<BIT>(send);
     }
 }
 __device__ __forceinline__ double wave_reduce_scatter32(double* acc) {
@@ -56,7 +83,7 @@ __device__ __forceinline__ double wave_reduce_scatter32(double* acc) {
     rs_step<4, 8>(acc, lane);
     rs_step<2, 4>(acc, lane);
     rs_step<1, 2>(acc, lane);
-    return acc[0] + __shfl_xor(acc[0], 1);
+    return acc[0] + xor_lane<1>(acc[0]);
 }
 
 // rows: partials[blockIdx.x][32]

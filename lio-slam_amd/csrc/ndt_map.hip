@@ -828,8 +828,11 @@ __device__ __forceinline__ unsigned long long same_digit_lanes(unsigned d, bool 
     }
     return m;
 }
-// LDS histogram add with same-digit lanes of a wave combined first (a LiDAR ring's consecutive points share their digit:
-// plain LDS atomics would serialise 64 ways)
+// LDS histogram add with RUNS of same-digit lanes combined first (a LiDAR ring's consecutive points share their digit:
+// plain LDS atomics would serialise 64 ways).  Only the first lane of a run adds, the run's length: one lane shift, two
+// ballots and a find-first-set instead of the nine ballots of a full same-digit match (round 3: the element kernel spent
+// more on that match, four digits per point, than on its memory traffic).  Separate runs of one digit in a wave meet in the
+// LDS atomic unit, which is exact either way.  Inactive lanes are a suffix of the wave (act = index < n).
 __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act) {
     const unsigned long long am = __ballot(act);
     if (!am) return;
@@ -839,8 +842,13 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* h, unsigned d, bool act)
         if (lane == __ffsll((long long)am) - 1) atomicAdd(&h[d0], (uint32_t)__popcll(am));
         return;
     }
-    const unsigned long long m = same_digit_lanes(d, act);
-    if (act && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(m));
+    const unsigned dk = act ? d : 0xFFFFFFFFu;
+    const unsigned prev = __shfl_up(dk, 1);
+    const bool head = act && (lane == 0 || prev != dk);
+    const unsigned long long stops = __ballot(head) | ~am;                   // run heads and the inactive tail
+    const unsigned long long rest = lane == 63 ? 0ull : stops >> (lane + 1);
+    const uint32_t run = rest ? (uint32_t)__ffsll((long long)rest) : (uint32_t)(64 - lane);
+    if (head) atomicAdd(&h[d], run);
 }
 
 #define OS_ITEMS 16                  // elements per thread of a tile: 4096 per tile; small batches use OS_ITEMS_SMALL (1024 per tile)

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const double* _
                                                                 SolveParams sp, EvalParams ep, double* __restrict__ partials, InitPose init, PeerWait pw, AosIn aos) {
     static_assert(sizeof(GnState) % 8 == 0, "GnState is copied as 8-byte words");
     constexpr int ST_WORDS = (int)(sizeof(GnState) / 8);
-    __shared__ double sm[RES1_THREADS / 32][ACC_N + 1];
+    __shared__ double sm[32][ACC_N + 1];
     __shared__ GnState sst;
     STAMP(0);
     // The first thirteen words of the argument block — everything up to `mode` — arrive in scalar registers with the wave
@@ -391,14 +391,14 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const double* _
         if (threadIdx.x < ST_WORDS) ((double*)&sst)[threadIdx.x] = use_init ? (threadIdx.x < 12 ? init.Rt[threadIdx.x] : 0.0) : sword;
     };
     bool rows_ok = true;                // (sharded loop: the rows are the ranks' rows in this rank's mailbox, once they are all there)
-    if (n_prev > 0 && has_pw) { store_state(); rows_ok = peer_gather<16>(pw, prev_partials, sm); }      // (ends with a barrier too)
+    if (n_prev > 0 && has_pw) { store_state(); rows_ok = peer_gather<32>(pw, prev_partials, sm); }      // (ends with a barrier too)
     else if (n_prev > 0) row_group_sums32_on512(prev_partials, n_prev, sm, store_state);      // ends with a barrier: sst is complete too
     else { store_state(); __syncthreads(); }
     STAMP(1);
     // (uniform) the rest of the previous step runs in the block's first wave, with no block barrier until the pose is out:
     // column tree, world-frame sums -> H, b (sst still holds the pose the rows were computed at), Gauss-Newton step
     if (n_prev > 0 && threadIdx.x < 64 && !sst.done) {
-        if (rows_ok) wave0_finish<16>(sm, &sst, sp, true);
+        if (rows_ok) wave0_finish<32>(sm, &sst, sp, true);
         else if (threadIdx.x == 0) { sst.status = NDT_ERR_COMM; sst.done = 1; }
     }
     STAMP(2);
@@ -725,39 +725,35 @@ __device__ __forceinline__ void row_group_sums(const double* __restrict__ partia
     sm[r][c] = v;
     __syncthreads();
 }
-// row_group_sums<32> on a 512-thread block, same bits: thread (r, c) keeps the sums of row groups r and r + 16 apart and
-// adds them as the tree's first level would (a group's running sum starts at +0 and can never become -0, so the
-// zero padding the 1024-thread form adds is immaterial).  Leaves 16 sums per column: the tree goes on from its second level.
+// row_group_sums<32> on a 512-thread block, same bits: thread (r = tid / 16, c2 = tid % 16) adds rows r, r + 32, ... of the
+// column PAIR (2 c2, 2 c2 + 1) — the same rows in the same order as thread (r, c) of the 1024-thread form, two columns at a
+// time, so that every row read is a 16-byte load: 8-byte accesses go through the L1 at 0.54-0.70x the 16-byte rate
+// (MI355X_MICROARCH.md), and these 59 KB per block sit on every iteration's critical path (round 3; the 8-byte form kept
+// the two halves of 16 groups in one thread instead).  Leaves all 32 group sums per column: the tree starts at its first level.
 // `after_loads` runs once, after the first (usually the only) batch of row reads has been requested and before any of
 // them is used: work that waits for an earlier read goes there without holding the row reads back.
 template <class F>
 __device__ __forceinline__ void row_group_sums32_on512(const double* __restrict__ partials, int n_partials, double (*sm)[ACC_N + 1], F&& after_loads) {
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int c2 = threadIdx.x & 15, r = threadIdx.x >> 4;
     double va = 0.0, vb = 0.0;
     bool first = true;
     for (int i0 = r; i0 < n_partials; i0 += 32 * 8) {
-        // (all sixteen reads unconditional, from a clamped row, and masked afterwards: no branch between them, one wait)
-        double x[8], y[8];
+        // (all eight reads unconditional, from a clamped row, and masked afterwards: no branch between them, one wait)
+        double2 x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 32 * u, j = i + 16;
-            x[u] = partials[(size_t)min(i, n_partials - 1) * ACC_N + c];
-            y[u] = partials[(size_t)min(j, n_partials - 1) * ACC_N + c];
-        }
+        for (int u = 0; u < 8; ++u) x[u] = *(const double2*)(partials + (size_t)min(i0 + 32 * u, n_partials - 1) * ACC_N + 2 * c2);
         if (first) { after_loads(); first = false; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 32 * u, j = i + 16;
-            x[u] = i < n_partials ? x[u] : 0.0;
-            y[u] = j < n_partials ? y[u] : 0.0;
-        }
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 32 * u >= n_partials) x[u] = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) va += x[u];
+        for (int u = 0; u < 8; ++u) va += x[u].x;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vb += y[u];
+        for (int u = 0; u < 8; ++u) vb += x[u].y;
     }
     if (first) after_loads();
-    sm[r][c] = va + vb;
+    sm[r][2 * c2] = va;
+    sm[r][2 * c2 + 1] = vb;
     __syncthreads();
 }
 // the fixed binary tree over the RG sums of column `c`: level o adds entry r + o to entry r for r < o, o = RG/2 .. 1
