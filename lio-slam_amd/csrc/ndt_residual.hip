@@ -347,11 +347,15 @@ __device__ __forceinline__ bool peer_gather(const PeerWait& pw, const double* ro
 // Diagnostic build only (-DNDT_STAMPS, tools/exp_stamps.py): s_memtime at the phase boundaries of the chained launch, from
 // thread 0 of two blocks, into a buffer no other code reads.  The product library is built without it.
 #ifdef NDT_STAMPS
+__device__ unsigned long long g_ndt_wstamps[8][4];      // block 100, per wave: pass start, pass end, butterfly end
+#define WSTAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 100) g_ndt_wstamps[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ndt_debug_wstamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ndt_wstamps), sizeof(g_ndt_wstamps)); }
 __device__ unsigned long long g_ndt_stamps[2][8];
 #define STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) g_ndt_stamps[blockIdx.x ? 1 : 0][k] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int ndt_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ndt_stamps), sizeof(g_ndt_stamps)); }
 #else
 #define STAMP(k) do { } while (0)
+#define WSTAMP(k) do { } while (0)
 #endif
 static_assert(offsetof(GnState, R) == 0 && offsetof(GnState, t) == 72, "InitPose fills the first twelve words of GnState");
 
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const double* _
     STAMP(3);
     if (blockIdx.x == 0 && threadIdx.x < ST_WORDS) ((double*)st_out)[threadIdx.x] = ((const double*)&sst)[threadIdx.x];
     if (sst.done) return;
+    WSTAMP(0);
     Pose P;
 #pragma unroll
     for (int j = 0; j < 9; ++j) P.R[j] = sst.R[j];
@@ -430,8 +435,10 @@ __global__ __launch_bounds__(RES1_THREADS) void k_residual_chain(const double* _
         }
     }
     STAMP(4);
+    WSTAMP(1);
     block_store_row<RES1_THREADS>(acc, partials + (size_t)blockIdx.x * ACC_N);
     STAMP(5);
+    WSTAMP(2);
 }
 
 // Offline replay (BASELINE.json configs[4]): blockIdx.y = alignment problem ("pair"), blockIdx.x = block of that
@@ -483,6 +490,8 @@ int residual_grid(size_t n, int n_cu, size_t problems, int nearby) {
         // 0.72 -> 0.53 ms per 10-iteration align against a 2048-block grid)
         size_t g = (n + RES1_THREADS - 1) / RES1_THREADS;
         const size_t cap = (size_t)n_cu;
+        // (rounding a nearly full grid up to one block per CU with the points dealt evenly — 256 blocks of 460 instead of 230 of
+        // 512 — measured worse in rounds 2 and 3: chained launch 8.12 -> 8.38 us, the pass alone unchanged)
         return (int)(g < 1 ? 1 : g > cap ? cap : g);
     }
     // Batched launches: 256-thread blocks, two resident per CU (241 VGPRs), each lane works through `ppt` points.  The
@@ -771,10 +780,32 @@ __device__ __forceinline__ double column_tree(double (*sm)[ACC_N + 1], int c) {
 // The block's first wave (all 64 lanes), after the barrier that made the RG sums per column visible: column tree, the
 // raw row -> H, b at the state's pose (one lane per entry; also stored in st->acc), and the Gauss-Newton step.  Only
 // wave-level ordering in here: LDS operations of one wave execute in issue order.  sm has at least 4 rows.
+// column_tree<32> by all 64 lanes of a wave, same tree, same bits: lane c + 32 h takes the groups 8 h .. 8 h + 7 and their
+// partners 16 above (the tree's first level), the two halves meet through one row swap per value (second level:
+// v[k] + v[k + 8]), lanes < 32 finish the last three levels.  Half the LDS reads and adds of the one-lane-per-column form
+// on the chained launch's critical path.  Returns the column total in lanes < 32.
+__device__ __forceinline__ double column_tree32_wave(double (*sm)[ACC_N + 1], int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = sm[8 * h + k][c] + sm[8 * h + k + 16][c];      // level 16
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = swap_add32(v[k], v[k]);                          // level 8: lanes < 32 get v_h0[k] + v_h1[k]
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < o; ++k) v[k] += v[k + o];
+    return v[0];
+}
 template <int RG>
 __device__ __forceinline__ void wave0_finish(double (*sm)[ACC_N + 1], GnState* st, const SolveParams& sp, bool do_solve) {
     const int lane = threadIdx.x & 63;
-    if (lane < ACC_N) sm[0][lane] = column_tree<RG>(sm, lane);      // a lane reads and writes its own column only
+    if constexpr (RG == 32) {
+        const double tot = column_tree32_wave(sm, lane);               // (all 64 lanes; a lane reads its own column only)
+        if (lane < ACC_N) sm[0][lane] = tot;
+    } else {
+        if (lane < ACC_N) sm[0][lane] = column_tree<RG>(sm, lane);      // a lane reads and writes its own column only
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     STAMP(6);

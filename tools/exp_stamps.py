@@ -22,3 +22,11 @@ for b in range(2):
     d = np.diff(st[b, :6])
     print("  inside wave 0: tree", int(st[b, 6] - st[b, 1]), "H,b", int(st[b, 7] - st[b, 6]), "step", int(st[b, 2] - st[b, 7]))
     print("block", [0, 100][b], {n: int(v) for n, v in zip(names, d)}, "total cycles", int(st[b, 5] - st[b, 0]), "(100 MHz ticks x ? -> see s_memtime unit)")
+
+wb = (ctypes.c_ulonglong * 32)()
+if hasattr(la.lib(), "ndt_debug_wstamps") and la.lib().ndt_debug_wstamps(wb) == 0:
+    ws = np.array(list(wb), dtype=np.int64).reshape(8, 4)
+    t0 = ws[:, 0].min()
+    print("block 100, per wave (cycles after the first wave entered the pass): pass start / pass end / row stored")
+    for w_ in range(8):
+        print("  wave", w_, int(ws[w_, 0] - t0), int(ws[w_, 1] - t0), int(ws[w_, 2] - t0))
