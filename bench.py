@@ -178,6 +178,7 @@ def large_map_workload(rank=0, world=1, dist=None):
     return dict(np.load(path))
 
 
+SHARDED_WATCHDOG_S = float(os.environ.get("NDT_BENCH_WATCHDOG_S", "240"))     # bench.py's sharded section: see main()
 REPLAY_SCANS, REPLAY_HYP = 512, 8          # BASELINE.json configs[4] / SURVEY.md §8(d): 4096 pairs = 512 scans x 8 hypotheses
 
 
@@ -845,18 +846,39 @@ def main():
         for d in dev[1:]:
             d.free()
         if multi:
-            # ---- the multi-GPU evidence, in the driver's one command (also at N = 1, so that the curves have an origin)
+            # ---- the multi-GPU evidence, in the driver's one command (also at N = 1, so that the curves have an origin).
+            # The replay job first (independent units, no collective: nothing in it can wait for another rank), then the
+            # sharded source, whose collectives have never met multi-GPU hardware: a watchdog prints the line as it stands —
+            # `value` and everything above are complete by then — if that section does not finish, so that a collective
+            # that hangs costs its own numbers and not the whole run.
+            rf = replay_full_section(la, local, w, rp, a, rank, world, dist, use_dist)
+            rf["n_gpus"] = world
+            out["replay_full"] = rf
             lm = large_map_workload(rank, dworld, dist)
             nl = la.NDT(device=local, nearby=a.nearby, max_iterations=a.iters, eps=0.0, final_eval=0)
             nl.set_target(lm["map"]); nl.synchronize()
+            if use_dist:
+                dist.barrier()
+
+            def give_up():
+                if rank == 0:
+                    out["sharded"] = {"error": f"the sharded section did not finish within {SHARDED_WATCHDOG_S} s (a collective that never completed?); "
+                                               "the rest of the line is complete", "n_gpus": world}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            import threading
+            dog = threading.Timer(SHARDED_WATCHDOG_S, give_up)
+            dog.daemon = True
+            dog.start()
+            if os.environ.get("NDT_BENCH_TEST_HANG"):          # rehearsal of the watchdog: the section never finishes
+                time.sleep(1e6)
             sh, _, _ = sharded_section(la, nl, lm["scan"], lm["guess"], lm["T_true"], a, rank, world, dist, use_dist, ("p2p", "rccl"))
+            dog.cancel()
             sh["voxels"] = int(nl.num_voxels()); sh["map_points"] = int(len(lm["map"])); sh["n_gpus"] = world
             out["sharded"] = sh
             if not extras:
                 nl.close(); nl = None
-            rf = replay_full_section(la, local, w, rp, a, rank, world, dist, use_dist)
-            rf["n_gpus"] = world
-            out["replay_full"] = rf
     else:
         # ---- --mode sharded: configs[3] as the headline of the line (value = the chosen collective's rate)
         lm = large_map_workload(rank, dworld, dist)
