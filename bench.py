@@ -119,9 +119,11 @@ def committed_counters():
 
 
 def pose_error(T, T_ref):
+    """(metres, radians); the angle from atan2 of the skew part and the trace (arccos of the trace alone stops resolving at 1e-8)"""
     d = np.linalg.inv(T_ref) @ T
-    c = min(1.0, max(-1.0, (np.trace(d[:3, :3]) - 1.0) / 2.0))
-    return float(np.linalg.norm(d[:3, 3])), float(np.arccos(c))
+    R = d[:3, :3]
+    s = 0.5 * float(np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]))
+    return float(np.linalg.norm(d[:3, 3])), float(np.arctan2(s, 0.5 * (float(np.trace(R)) - 1.0)))
 
 
 def load_workload(index, rank, world, dist, small):

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import pose_error, rel_err
+from conftest import pose_error, rel_err, TIGHT_H, TIGHT_T, TIGHT_R
 
 pytestmark = pytest.mark.gpu
 
@@ -31,14 +31,14 @@ def test_batch_matches_oracle_and_single():
         assert r["status"] == 0 and ro["rc"] == 0
         assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
         dt, dr = pose_error(r["T"], ro["T"])
-        assert dt < 1e-4 and dr < 1e-5
-        assert rel_err(r["H"], ro["H"]) < 1e-5 and r["n_effective"] == ro["n_effective"]
+        assert dt < TIGHT_T and dr < TIGHT_R
+        assert rel_err(r["H"], ro["H"]) < TIGHT_H and r["n_effective"] == ro["n_effective"]
         et, er = pose_error(r["T"], poses[pair_scan[p]])
         assert et < 0.05 and er < 0.01
         n.set_source(scans[pair_scan[p]])                           # the single-scan path agrees with the batch
         rs = n.align(guesses[p])
         dt, dr = pose_error(r["T"], rs["T"])
-        assert dt < 1e-9 and dr < 1e-7 and rel_err(r["H"], rs["H"]) < 1e-10
+        assert dt < 1e-9 and dr < 1e-9 and rel_err(r["H"], rs["H"]) < 1e-10
     assert res[6]["status"] == -5 and res[6]["iterations"] == 0
     # without pair_scan: one scan per pair
     res2 = n.align_batch(scans[:3], [guesses[0], guesses[2], guesses[4]])

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, pose_error, rel_err
+from conftest import ROOT, pose_error, rel_err, TIGHT_H, TIGHT_T, TIGHT_R
 
 pytestmark = pytest.mark.gpu
 EXE = os.path.join(ROOT, "lio-slam_amd", os.environ.get("NDT_TEST_EXE_DIR", ""), "facade_test")   # (NDT_TEST_EXE_DIR=asan: the host-ASan builds of tools/build_asan.sh)
@@ -36,8 +36,11 @@ def test_cpp_facade_matches_oracle(tmp_path):
     r = o.align(guess32.astype(np.float64))
     assert int(st[1]) == 0 and int(st[3]) == int(r["converged"]) and int(st[5]) == r["iterations"]
     dt, dr = pose_error(T, r["T"])
-    assert dt < 1e-4 and dr < 1e-5
-    assert rel_err(H, r["H"]) < 1e-5
+    assert dt < TIGHT_T and dr < TIGHT_R
+    # The guess is the reference's Matrix4f (utility.cc:34): a rotation rounded to float32 is orthonormal to 3e-8 only, and the
+    # engine's factored H (world-frame sums rotated back) equals the oracle's direct J^T Sigma^-1 J for an
+    # orthonormal R — so here, and only here, H shows the guess's own rounding (measured 4.5e-8; 1e-14 with a float64 guess)
+    assert rel_err(H, r["H"]) < 1e-6
     # alignBatch: pair 0 = the same problem (same pose up to the batch's summation order), pair 2 = pair 0 bit for bit
     bt = lines[3].split()
     assert bt[0] == "batch" and int(bt[1]) == 0 and int(bt[2]) == 0 and int(bt[3]) == r["iterations"] and float(bt[4]) < 1e-9 and int(bt[5]) == 1
@@ -47,9 +50,9 @@ def test_cpp_facade_matches_oracle(tmp_path):
     o.set_params(max_iterations=35, eps=0.01)
     rp = o.pcl_align(guess32.astype(np.float64), step_size=0.1)
     assert int(st2[1]) == 0 and int(st2[3]) == int(rp["converged"]) and int(st2[5]) == rp["iterations"]
-    assert abs(float(st2[7]) - rp["trans_probability"]) <= 1e-6 * abs(rp["trans_probability"])
+    assert abs(float(st2[7]) - rp["trans_probability"]) <= TIGHT_H * abs(rp["trans_probability"])
     dt, dr = pose_error(Tp, rp["T"])
-    assert dt < 1e-6 and dr < 1e-7
+    assert dt < TIGHT_T and dr < TIGHT_R
     # process.cc:94-95 written as the reference has them, through a 16-float column-major matrix type passed by value
     m4 = lines[6].split()
     assert m4[0] == "matrix4f" and float(m4[1]) == 0.0

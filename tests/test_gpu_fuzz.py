@@ -1,12 +1,13 @@
 """Randomised differential test: the HIP engine against the CPU oracle over seeded random scenes and configurations
 (resolution, key rule, NEARBY1/7, voxel validity and gate thresholds, eigenvalue floor), with ragged input thrown in
 (non-finite points, duplicates, points outside the key range, planar and collinear voxels, empty merges).  Same bars
-as test_gpu_parity.py: keys, counts, validity, cell assignment and gate masks bit for bit; H, b, chi2 at 1e-5; poses
-at 1e-4 m / 1e-5 rad."""
+as test_gpu_parity.py for one pass: keys, counts, validity, cell assignment and gate masks bit for bit; H, b, chi2 at 1e-10.
+Aligned poses of the Gauss-Newton loop stay at the north star's 1e-4 m / 1e-5 rad here: random scenes with a dozen effective
+points reach Hessians with condition numbers of 1e13, which turn a last-bit difference into micrometres (tools/fuzz_diag.py)."""
 import numpy as np
 import pytest
 
-from conftest import pose_error, rel_err
+from conftest import pose_error, rel_err, TIGHT_H, TIGHT_T, TIGHT_R
 
 pytestmark = pytest.mark.gpu
 
@@ -63,8 +64,8 @@ def test_random_scene_and_config(seed):
     vg, vo = n.export_voxels(), o.export_voxels()
     assert n.num_voxels() == o.num_voxels() == len(vo["keys"])
     assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"]) and np.array_equal(vg["valid"], vo["valid"])
-    np.testing.assert_allclose(vg["mean"], vo["mean"], rtol=0, atol=1e-9 * max(1.0, res))
-    np.testing.assert_allclose(vg["cov"], vo["cov"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(vg["mean"], vo["mean"], rtol=0, atol=1e-12 * max(1.0, res))
+    assert np.max(np.abs(vg["cov"] - vo["cov"]) / np.maximum(np.abs(vo["cov"]).max(axis=(1, 2), keepdims=True), 1e-300)) < 1e-10
     # source: a subset of the scene seen from a perturbed pose
     T_true = _se3(rng, 2.0, 0.3); T_true[:3, 3] += origin
     sel = rng.choice(len(pts), min(len(pts), int(rng.integers(500, 6000))), replace=False)
@@ -80,7 +81,7 @@ def test_random_scene_and_config(seed):
     eg, eo = n.eval(guess), o.eval(guess)
     assert eg["n_effective"] == eo["n_effective"]
     if eo["n_effective"] > 0:
-        assert rel_err(eg["H"], eo["H"]) < 1e-5 and rel_err(eg["b"], eo["b"]) < 1e-5 and abs(eg["chi2"] - eo["chi2"]) <= 1e-5 * abs(eo["chi2"])
+        assert rel_err(eg["H"], eo["H"]) < TIGHT_H and rel_err(eg["b"], eo["b"]) < 1e-8 and abs(eg["chi2"] - eo["chi2"]) <= TIGHT_H * abs(eo["chi2"])
     rg, ro = n.align(guess, check=False), o.align(guess)
     assert rg["rc"] == ro["rc"]
     if ro["rc"] == 0:
@@ -157,10 +158,10 @@ def test_random_pcl_mode(seed):
     p = la.pcl_vector_from_matrix(guess)
     rn, ro = n.pcl_eval(p, **prm), o.pcl_eval(p, **prm)
     assert rn["n_neighbours"] == ro["n_neighbours"] > 0
-    assert abs(rn["score"] - ro["score"]) <= 1e-6 * abs(ro["score"])
-    assert rel_err(rn["g"], ro["g"]) < 1e-6 and rel_err(rn["H"], ro["H"]) < 1e-6
+    assert abs(rn["score"] - ro["score"]) <= TIGHT_H * abs(ro["score"])
+    assert rel_err(rn["g"], ro["g"]) < 1e-8 and rel_err(rn["H"], ro["H"]) < TIGHT_H
     ra, rb = n.pcl_align(guess, **prm), o.pcl_align(guess, **prm)
     assert ra["rc"] == rb["rc"] == 0 and ra["iterations"] == rb["iterations"] and ra["evaluations"] == rb["evaluations"]
     dt, dr = pose_error(ra["T"], rb["T"])
-    assert dt < 1e-6 and dr < 1e-7, (dt, dr)
+    assert dt < 1e-8 and dr < 1e-8, (dt, dr)
     n.close()

@@ -34,7 +34,7 @@ def test_group_replay_matches_single_handle():
         for a, b in zip(res, ref):
             assert a["status"] == b["status"] == 0 and a["iterations"] == b["iterations"]
             dt, dr = pose_error(a["T"], b["T"])
-            assert dt < 1e-9 and dr < 1e-7 and rel_err(a["H"], b["H"]) < 1e-10        # batch size differs: summation order only (the angle metric resolves ~1e-8)
+            assert dt < 1e-9 and dr < 1e-9 and rel_err(a["H"], b["H"]) < 1e-10        # batch size differs: summation order only
         again = g.align_batch(scans, guesses, pair_scan)
         assert all(np.array_equal(a["T"], b["T"]) for a, b in zip(res, again))       # deterministic
         # more members than pairs, one scan per pair

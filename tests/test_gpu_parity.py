@@ -1,18 +1,20 @@
 """GPU parity: the HIP engine through its C ABI against the CPU oracle, on the same seeded inputs.
 
-Bars (BASELINE.json north_star): voxel keys / cell assignment bit-exact; H and b within 1e-5 relative;
-final pose within 1e-4 m / 1e-5 rad.  Voxel statistics are float64 sums in a different (fixed) order
-than the oracle's, so they are compared at 1e-9.
+North star (BASELINE.json): voxel keys / cell assignment bit-exact; H and b within 1e-5 relative; final pose within
+1e-4 m / 1e-5 rad.  The bars used here are the measured ones of conftest.py (TIGHT_*: 1e-10 on H, b, chi2; 1e-9 m / 1e-9 rad
+on poses): oracle and golden vectors carry the same float32 table payload as the engine, so what is left is float64
+summation order.  Voxel statistics are float64 sums in a different (fixed) order than the oracle's: means to 1e-12 m,
+covariances to 1e-10 of the voxel's largest entry.
 """
 import numpy as np
 import pytest
 
-from conftest import pose_error, rel_err
+from conftest import pose_error, rel_err, TIGHT_H, TIGHT_T, TIGHT_R, Q0_H
 
 pytestmark = pytest.mark.gpu
 
-H_TOL = 1e-5        # north-star bar for H and b
-POSE_T, POSE_R = 1e-4, 1e-5
+H_TOL = TIGHT_H     # (north star: 1e-5)
+POSE_T, POSE_R = TIGHT_T, TIGHT_R     # (north star: 1e-4 m, 1e-5 rad)
 
 
 @pytest.fixture(scope="module")
@@ -33,11 +35,12 @@ def _cmp_maps(g, o):
     assert np.array_equal(g["keys"], o["keys"])               # bit-exact voxel keys
     assert np.array_equal(g["counts"], o["counts"])
     assert np.array_equal(g["valid"], o["valid"])
-    np.testing.assert_allclose(g["mean"], o["mean"], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(g["cov"], o["cov"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(g["mean"], o["mean"], rtol=0, atol=1e-12)
+    assert np.max(np.abs(g["cov"] - o["cov"]) / np.maximum(np.abs(o["cov"]).max(axis=(1, 2), keepdims=True), 1e-300)) < 1e-10
     v = o["valid"].astype(bool)
     scale = np.abs(o["info"][v]).max(axis=(1, 2), keepdims=True)
-    assert np.max(np.abs(g["info"][v] - o["info"][v]) / scale) < 5e-7   # float32 payload, 1 ulp slack
+    d = np.abs(g["info"][v] - o["info"][v]) / scale
+    assert np.max(d) < 5e-7 and np.mean(d > 1e-10) < 1e-4    # float32 payload: a rounding may land on the other side in a rare entry
 
 
 def _cmp_eval(eg, eo):
@@ -86,20 +89,21 @@ def test_golden_pair(mods, golden, nearby):
     assert e["n_effective"] == int(g[f"neff_{tag}"])
     assert rel_err(e["H"], g[f"H_{tag}"]) < H_TOL
     assert rel_err(e["b"], g[f"b_{tag}"]) < H_TOL
+    assert abs(e["chi2"] - float(g[f"chi2_{tag}"])) < H_TOL * abs(float(g[f"chi2_{tag}"]))
     # ... and against the PURE float64 vectors (q0: no float32 rounding of the table payload anywhere): the engine's float32
     # payload moves H, b by 1e-9 ... 4e-8 relative, far inside the north star's 1e-5, and never flips a gate on this pair
     q0 = f"q0_n{nearby}"
     assert np.array_equal(la.unpack_keys(keys), g[f"cells_{q0}"]) and np.array_equal(masks, g[f"masks_{q0}"])
     assert e["n_effective"] == int(g[f"neff_{q0}"])
-    assert rel_err(e["H"], g[f"H_{q0}"]) < H_TOL and rel_err(e["b"], g[f"b_{q0}"]) < H_TOL
-    assert abs(e["chi2"] - float(g[f"chi2_{q0}"])) < H_TOL * abs(float(g[f"chi2_{q0}"]))
+    assert rel_err(e["H"], g[f"H_{q0}"]) < Q0_H and rel_err(e["b"], g[f"b_{q0}"]) < Q0_H
+    assert abs(e["chi2"] - float(g[f"chi2_{q0}"])) < Q0_H * abs(float(g[f"chi2_{q0}"]))
     if nearby == 7:
         n.configure(max_iterations=6, eps=0.0, final_eval=0)
         r = n.align(g["guess"])
         dt, dr = pose_error(r["T"], g["poses_q1"][5])
         assert dt < POSE_T and dr < POSE_R
         dt, dr = pose_error(r["T"], g["poses_q0"][5])              # the pure-float64 iteration lands at the same pose
-        assert dt < POSE_T and dr < POSE_R
+        assert dt < 1e-6 and dr < 1e-6                             # (to what the float32 payload moves it: measured 3e-8 m)
 
 
 @pytest.mark.parametrize("index,rule,res", [(0, 0, 1.0), (1, 0, 1.0), (1, 1, 1.0), (0, 0, 0.7)])
@@ -168,7 +172,7 @@ def test_incndt3d_options_parity(mods):
         _cmp_eval(n.eval(c["guess"]), o.eval(c["guess"]))
         rg, ro = n.align(c["guess"]), o.align(c["guess"])
         assert rg["iterations"] == ro["iterations"]
-        assert np.abs(rg["T"][:3, 3] - ro["T"][:3, 3]).max() < 1e-4
+        assert np.abs(rg["T"][:3, 3] - ro["T"][:3, 3]).max() < POSE_T
         n.close()
 
 

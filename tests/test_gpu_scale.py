@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import lio_slam_amd as la
-from conftest import pose_error, rel_err
+from conftest import pose_error, rel_err, TIGHT_H, TIGHT_T, TIGHT_R
 from lio_slam_amd import synth
 from oracle.oracle import Oracle
 
@@ -33,9 +33,10 @@ def test_20m_point_map_and_2m_point_source(small2):
     assert n.num_voxels() == o.num_voxels() > 500_000
     vg, vo = n.export_voxels(), o.export_voxels()
     assert np.array_equal(vg["keys"], vo["keys"]) and np.array_equal(vg["counts"], vo["counts"]) and np.array_equal(vg["valid"], vo["valid"])
-    assert rel_err(vg["mean"], vo["mean"]) < 1e-9
+    assert np.abs(vg["mean"] - vo["mean"]).max() < 1e-10            # metres, at coordinates up to 3 km
     sel = vo["valid"].astype(bool)
-    assert np.max(np.abs(vg["info"][sel] - vo["info"][sel]) / np.maximum(np.abs(vo["info"][sel]).max(axis=(1, 2), keepdims=True), 1e-30)) < 1e-5
+    d = np.abs(vg["info"][sel] - vo["info"][sel]) / np.maximum(np.abs(vo["info"][sel]).max(axis=(1, 2), keepdims=True), 1e-30)
+    assert np.max(d) < 5e-7 and np.mean(d > 1e-10) < 1e-4          # float32 payload: a rounding may land on the other side in a rare entry
     # 2 M source points: the scan seen from 18 of the tiles, in one sensor frame
     T = c["T_true"]
     parts = []
@@ -50,10 +51,10 @@ def test_20m_point_map_and_2m_point_source(small2):
     assert np.array_equal(kg, ko) and np.array_equal(mg, mo)                # 2 M cell assignments and gate masks, bit for bit
     eg, eo = n.eval(c["guess"]), o.eval(c["guess"])
     assert eg["n_effective"] == eo["n_effective"] > 200_000      # the 200 k-point tiles are sparse: few voxels reach 6 points
-    assert rel_err(eg["H"], eo["H"]) < 1e-5 and rel_err(eg["b"], eo["b"]) < 1e-5
+    assert rel_err(eg["H"], eo["H"]) < TIGHT_H and rel_err(eg["b"], eo["b"]) < TIGHT_H
     rg, ro = n.align(c["guess"]), o.align(c["guess"])
     dt, dr = pose_error(rg["T"], ro["T"])
-    assert rg["iterations"] == ro["iterations"] and dt < 1e-4 and dr < 1e-5
+    assert rg["iterations"] == ro["iterations"] and dt < TIGHT_T and dr < TIGHT_R
     et, _ = pose_error(rg["T"], T)
     assert et < 0.2                                                       # sparse map: the optimum itself sits ~9 cm from the truth
 
@@ -75,7 +76,7 @@ def test_4096_pair_replay(small2):
         o.set_source(scans[pair_scan[p]])
         ro = o.align(guesses[p])
         dt, dr = pose_error(res[p]["T"], ro["T"])
-        assert dt < 1e-4 and dr < 1e-5, (p, dt, dr)
-        assert rel_err(res[p]["H"], ro["H"]) < 1e-5
+        assert dt < 1e-8 and dr < 1e-8, (p, dt, dr)               # (hypotheses up to 0.5 m / 5 deg: ten iterations from far away)
+        assert rel_err(res[p]["H"], ro["H"]) < 1e-8
     again = n.align_batch_resident(guesses, pair_scan)                           # deterministic: same bits on a second run
     assert all(np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"]) for a, b in zip(res, again))
