@@ -36,7 +36,7 @@ def _se3(rng, dt, dr):
     return T
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_scene_and_config(seed):
     import lio_slam_amd as la
     from oracle.oracle import Oracle
@@ -104,7 +104,7 @@ def test_random_scene_and_config(seed):
     n.close()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_downsample(seed):
     """pcl::VoxelGrid on the device against the oracle: random leaf sizes and extrinsics, non-finite points, negative
     coordinates, from one point per cell to hundreds.  Same cells in the same (PCL index) order; centroids are float64
@@ -133,7 +133,7 @@ def test_random_downsample(seed):
     n.close()
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_pcl_mode(seed):
     """PCL compatibility mode against the oracle's PCL-literal restatement on random scenes: resolutions, outlier ratios,
     step sizes, both forms of the angular Hessian row, merges before the evaluation, non-finite source points."""
