@@ -409,6 +409,8 @@ static int ready(ndt_handle* h, bool keep_pending_records = false) {
     if (!h) return NDT_ERR_INVALID_ARG;
     if (!h->have_target || h->map.cap == 0) { h->err = "no target: call ndt_set_target first"; return NDT_ERR_NO_TARGET; }
     if (!h->have_source) { h->err = "no source: call ndt_set_source first"; return NDT_ERR_NO_SOURCE; }
+    // (the unpack below is a launch on the handle's stream: its device must be current, whatever the caller's thread had last)
+    H_TRY(hipSetDevice(h->cfg.device));
     return keep_pending_records ? NDT_OK : ensure_source_soa(h);
 }
 static EvalParams eval_params(const ndt_handle* h) {
@@ -1145,8 +1147,9 @@ int ndt_comm_size(const ndt_handle* h) {      // ranks of the attached communica
 }
 int ndt_comm_destroy(ndt_handle* h) {
     if (!h) return NDT_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->cfg.device);
     if (h->comm) { (void)hipStreamSynchronize(h->stream); g_rccl.destroy(h->comm); h->comm = nullptr; h->n_ranks = 1; }
-    if (h->px.local) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->stream); px_release(h); h->n_ranks = 1; }
+    if (h->px.local) { (void)hipStreamSynchronize(h->stream); px_release(h); h->n_ranks = 1; }
     return NDT_OK;
 }
 
